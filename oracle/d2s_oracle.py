@@ -1,0 +1,416 @@
+"""CPU ORACLE - test infrastructure, not product code.
+
+A plain-PyTorch (CPU, fp32) restatement of the reference's dense-to-sparse ViT training path, written
+as pure functions over a state dict whose keys are the reference's own state-dict keys.  Only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file; nothing under
+dense2sparse-vit_amd/ does (the product path has no CPU fallback and fails loudly without the HIP
+library).
+
+Parity status: PINNED.  tools/gen_golden.py imports the reference's unmodified
+vit_models/dynamic_vit.py, vit_models/peturbed_topk.py and losses.py in the survey container, loads
+the deterministic weights of dense2sparse-vit_amd/d2s/synth.py into the reference's own classes and
+stores inputs/outputs under tests/golden/; tests/test_oracle_golden.py checks every function below
+against those fixtures.
+
+Every function cites the reference lines it restates (paths relative to /root/reference).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------------------
+# configuration helper
+# --------------------------------------------------------------------------------------------------
+def make_cfg(img_size=224, patch=16, dim=384, depth=12, heads=6, mlp_ratio=4.0, num_classes=1000,
+             pruning_loc=(), token_ratio=(), small_predictor=False, loss_type="kl_div", init_n=None,
+             ln_eps=1e-6):
+    """Geometry of one student/teacher pair.  `init_n` reproduces the reference's hard-coded
+    `init_n = 14 * 14` (vit_models/dynamic_vit.py:828,852) when left at None for 224x224 inputs; the
+    keep count is always int(init_n * ratio) like the reference."""
+    n_patches = (img_size // patch) ** 2
+    return dict(img_size=img_size, patch=patch, dim=dim, depth=depth, heads=heads, mlp_ratio=mlp_ratio,
+                num_classes=num_classes, pruning_loc=tuple(pruning_loc), token_ratio=tuple(token_ratio),
+                small_predictor=small_predictor, loss_type=loss_type, n_patches=n_patches,
+                init_n=(14 * 14 if init_n is None else init_n), ln_eps=ln_eps)
+
+
+def keep_counts(cfg):
+    """vit_models/dynamic_vit.py:852 - num_keep_node = int(init_n * ratio)."""
+    return [int(cfg["init_n"] * r) for r in cfg["token_ratio"]]
+
+
+def student_param_shapes(cfg):
+    """(name, shape) for every parameter of VisionTransformerDiffPruning with the large LayerNorm
+    predictor (vit_models/dynamic_vit.py:684-722, 491-531) or the small LN predictor (:409-426)."""
+    D, C = cfg["dim"], cfg["num_classes"]
+    hid = int(D * cfg["mlp_ratio"])
+    out = [("cls_token", (1, 1, D)), ("pos_embed", (1, cfg["n_patches"] + 1, D)),
+           ("patch_embed.proj.weight", (D, 3, cfg["patch"], cfg["patch"])), ("patch_embed.proj.bias", (D,))]
+    for i in range(cfg["depth"]):
+        p = f"blocks.{i}."
+        out += [(p + "norm1.weight", (D,)), (p + "norm1.bias", (D,)),
+                (p + "attn.qkv.weight", (3 * D, D)), (p + "attn.qkv.bias", (3 * D,)),
+                (p + "attn.proj.weight", (D, D)), (p + "attn.proj.bias", (D,)),
+                (p + "norm2.weight", (D,)), (p + "norm2.bias", (D,)),
+                (p + "mlp.fc1.weight", (hid, D)), (p + "mlp.fc1.bias", (hid,)),
+                (p + "mlp.fc2.weight", (D, hid)), (p + "mlp.fc2.bias", (D,))]
+    out += [("norm.weight", (D,)), ("norm.bias", (D,)), ("head.weight", (C, D)), ("head.bias", (C,))]
+    for s in range(len(cfg["pruning_loc"])):
+        p = f"score_predictor.{s}."
+        if cfg["small_predictor"]:
+            out += [(p + "in_conv.0.weight", (D,)), (p + "in_conv.0.bias", (D,)),
+                    (p + "in_conv.1.weight", (D, D)), (p + "in_conv.1.bias", (D,))]
+            widths = [D, D // 2, D // 4, 1]
+            idx = [0, 1, 3, 4, 6, 7]
+        else:
+            out += [(p + "in_conv.0.weight", (D,)), (p + "in_conv.0.bias", (D,)),
+                    (p + "in_conv.1.weight", (4 * D, D)), (p + "in_conv.1.bias", (4 * D,))]
+            widths = [4 * D, 2 * D, D, D // 2, D // 4, 1]
+            idx = [0, 1, 3, 4, 6, 7, 9, 10, 12, 13]
+        for j in range(len(widths) - 1):
+            ln_i, fc_i = idx[2 * j], idx[2 * j + 1]
+            out += [(p + f"out_conv.{ln_i}.weight", (widths[j],)), (p + f"out_conv.{ln_i}.bias", (widths[j],)),
+                    (p + f"out_conv.{fc_i}.weight", (widths[j + 1], widths[j])),
+                    (p + f"out_conv.{fc_i}.bias", (widths[j + 1],))]
+    return out
+
+
+def teacher_param_shapes(cfg):
+    """VisionTransformerTeacher (vit_models/dynamic_vit.py:1070-1101): the student minus predictors."""
+    c = dict(cfg)
+    c["pruning_loc"] = ()
+    return student_param_shapes(c)
+
+
+# --------------------------------------------------------------------------------------------------
+# building blocks
+# --------------------------------------------------------------------------------------------------
+def patch_embed(sd, x, cfg):
+    """PatchEmbed.forward, vit_models/dynamic_vit.py:300-306: stride-16 conv, flatten(2), transpose."""
+    assert x.shape[2] == cfg["img_size"] and x.shape[3] == cfg["img_size"], "image size mismatch (:303-304)"
+    y = F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=cfg["patch"])
+    return y.flatten(2).transpose(1, 2)
+
+
+def embed_tokens(sd, x, cfg):
+    """vit_models/dynamic_vit.py:816-824 - patch embed, prepend CLS, add pos_embed (dropout p=0)."""
+    t = patch_embed(sd, x, cfg)
+    cls = sd["cls_token"].expand(t.shape[0], -1, -1)
+    return torch.cat((cls, t), dim=1) + sd["pos_embed"]
+
+
+def softmax_with_policy(attn, policy, eps=1e-6):
+    """Attention.softmax_with_policy, vit_models/dynamic_vit.py:195-214."""
+    B, N, _ = policy.shape
+    pol = policy.reshape(B, 1, 1, N)
+    eye = torch.eye(N, dtype=pol.dtype).view(1, 1, N, N)
+    pol = pol + (1.0 - pol) * eye
+    attn = attn - attn.max(dim=-1, keepdim=True)[0]
+    attn = attn.to(torch.float32).exp() * pol.to(torch.float32)
+    return (attn + eps / N) / (attn.sum(dim=-1, keepdim=True) + eps)
+
+
+def attention(sd, pre, x, heads, policy=None):
+    """Attention.forward, vit_models/dynamic_vit.py:216-236.  Returns (out, cls_row[B,H,n])."""
+    B, n, C = x.shape
+    dh = C // heads
+    qkv = F.linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"])
+    qkv = qkv.reshape(B, n, 3, heads, dh).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    a = (q @ k.transpose(-2, -1)) * (dh ** -0.5)
+    a = a.softmax(dim=-1) if policy is None else softmax_with_policy(a, policy)
+    o = (a @ v).transpose(1, 2).reshape(B, n, C)
+    o = F.linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+    return o, a[:, :, 0, :]
+
+
+def mlp(sd, pre, x):
+    """Mlp.forward, vit_models/dynamic_vit.py:169-175 (exact erf GELU, dropout p=0)."""
+    h = F.gelu(F.linear(x, sd[pre + "fc1.weight"], sd[pre + "fc1.bias"]))
+    return F.linear(h, sd[pre + "fc2.weight"], sd[pre + "fc2.bias"])
+
+
+def block(sd, i, x, cfg, policy=None):
+    """Block.forward, vit_models/dynamic_vit.py:263-283 (DropPath = identity at rate 0, :249)."""
+    p = f"blocks.{i}."
+    D, eps = cfg["dim"], cfg["ln_eps"]
+    y, cls_row = attention(sd, p + "attn.", F.layer_norm(x, (D,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps),
+                           cfg["heads"], policy)
+    x = x + y
+    x = x + mlp(sd, p + "mlp.", F.layer_norm(x, (D,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps))
+    return x, cls_row
+
+
+def predictor(sd, s, x, cfg):
+    """PredictorLG.forward with topk_selection=True, vit_models/dynamic_vit.py:536-560.
+    Large LN variant :491-531 (ReLU), small LN variant :409-426 (GELU).  nn.LayerNorm default eps 1e-5.
+    Returns (scores, keep_probs) each [B, n-1]."""
+    p = f"score_predictor.{s}."
+    small = cfg["small_predictor"]
+    act = F.gelu if small else F.relu
+    D = cfg["dim"]
+    h = F.layer_norm(x, (D,), sd[p + "in_conv.0.weight"], sd[p + "in_conv.0.bias"], 1e-5)
+    h = act(F.linear(h, sd[p + "in_conv.1.weight"], sd[p + "in_conv.1.bias"]))
+    B, N, C = h.shape
+    local_x = h[:, :, :C // 2]
+    global_x = torch.mean(h[:, :, C // 2:], dim=1, keepdim=True)
+    h = torch.cat([local_x, global_x.expand(B, N, C // 2)], dim=-1)
+    idx = [0, 1, 3, 4, 6, 7] if small else [0, 1, 3, 4, 6, 7, 9, 10, 12, 13]
+    nl = len(idx) // 2
+    for j in range(nl):
+        ln_i, fc_i = idx[2 * j], idx[2 * j + 1]
+        w = sd[p + f"out_conv.{ln_i}.weight"]
+        h = F.layer_norm(h, (w.shape[0],), w, sd[p + f"out_conv.{ln_i}.bias"], 1e-5)
+        h = F.linear(h, sd[p + f"out_conv.{fc_i}.weight"], sd[p + f"out_conv.{fc_i}.bias"])
+        if j < nl - 1:
+            h = act(h)
+    scores = h.flatten(-2, -1)
+    if cfg["loss_type"] in ("kl_div", "mse"):
+        keep_probs = F.softmax(scores, dim=-1)
+    else:
+        keep_probs = torch.sigmoid(scores)
+    return scores, keep_probs
+
+
+def select_topk(keep_probs, k):
+    """vit_models/dynamic_vit.py:858-862 - full descending argsort, split at k, sort each ascending."""
+    order = torch.argsort(keep_probs, dim=1, descending=True)
+    kept = torch.sort(order[:, :k], dim=1)[0]
+    dropped = torch.sort(order[:, k:], dim=1)[0]
+    return kept, dropped
+
+
+def select_topk_stable(keep_probs, k):
+    """Same selection with the tie rule spelled out (larger value first, equal values lowest index first),
+    independent of the sort implementation.  Used to pin the tie behaviour the HIP kernel implements."""
+    order = torch.sort(keep_probs, dim=1, descending=True, stable=True)[1]
+    kept = torch.sort(order[:, :k], dim=1)[0]
+    dropped = torch.sort(order[:, k:], dim=1)[0]
+    return kept, dropped
+
+
+def gather_pack(x, kept):
+    """vit_models/dynamic_vit.py:907-912 - keep CLS (row 0) and rows kept+1."""
+    B = x.shape[0]
+    pol = torch.cat([torch.zeros(B, 1, dtype=kept.dtype), kept + 1], dim=1)
+    return torch.gather(x, 1, pol.unsqueeze(-1).expand(-1, -1, x.shape[-1]))
+
+
+def batch_index_select(x, idx):
+    """vit_models/dynamic_vit.py:39-60."""
+    if x.dim() == 3:
+        B, N, C = x.shape
+        off = torch.arange(B, dtype=torch.long).view(B, 1) * N
+        return x.reshape(B * N, C)[(idx + off).reshape(-1)].reshape(B, idx.shape[1], C)
+    if x.dim() == 2:
+        B, N = x.shape
+        off = torch.arange(B, dtype=torch.long).view(B, 1) * N
+        return x.reshape(B * N)[(idx + off).reshape(-1)].reshape(B, idx.shape[1])
+    raise NotImplementedError
+
+
+# --------------------------------------------------------------------------------------------------
+# models
+# --------------------------------------------------------------------------------------------------
+def student_forward(sd, x, cfg, training=True):
+    """VisionTransformerDiffPruning.forward, vit_models/dynamic_vit.py:814-1015 (patch_score_threshold
+    None).  training: (logits, features, [pred_logits], [kept]); eval: (logits, [cls_attn], [pred_logits],
+    [kept]).  Also returns aux = dict(dropped=[...], keep_probs=[...], cls_attns=[...])."""
+    x = embed_tokens(sd, x, cfg)
+    counts = keep_counts(cfg)
+    pred_logits, kept_all, dropped_all, probs_all, cls_attns = [], [], [], [], []
+    stage = 0
+    for i in range(cfg["depth"]):
+        if i in cfg["pruning_loc"]:
+            scores, probs = predictor(sd, stage, x[:, 1:], cfg)
+            kept, dropped = select_topk(probs, counts[stage])
+            pred_logits.append(scores)
+            kept_all.append(kept)
+            dropped_all.append(dropped)
+            probs_all.append(probs)
+            x = gather_pack(x, kept)
+            stage += 1
+        x, cls_row = block(sd, i, x, cfg)
+        cls_attns.append(cls_row[:, :, 1:])
+    x = F.layer_norm(x, (cfg["dim"],), sd["norm.weight"], sd["norm.bias"], cfg["ln_eps"])
+    features = x[:, 1:]
+    logits = F.linear(x[:, 0], sd["head.weight"], sd["head.bias"])
+    aux = dict(dropped=dropped_all, keep_probs=probs_all, cls_attns=cls_attns)
+    if training:
+        return (logits, features, pred_logits, kept_all), aux
+    return (logits, cls_attns, pred_logits, kept_all), aux
+
+
+def teacher_forward(sd, x, cfg):
+    """VisionTransformerTeacher.forward, vit_models/dynamic_vit.py:1150-1176:
+    (logits, tokens[B,N,D], cls_attn[B,depth,H,N+1]) - CLS rows detached (:1165)."""
+    x = embed_tokens(sd, x, cfg)
+    rows = []
+    for i in range(cfg["depth"]):
+        x, cls_row = block(sd, i, x, cfg)
+        rows.append(cls_row.detach())
+    f = F.layer_norm(x, (cfg["dim"],), sd["norm.weight"], sd["norm.bias"], cfg["ln_eps"])
+    logits = F.linear(f[:, 0], sd["head.weight"], sd["head.bias"])
+    return logits, f[:, 1:], torch.stack(rows, dim=1)
+
+
+# --------------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------------
+def topk_mask(values, keep_ratio):
+    """MaskLoss.get_mask_from_pred_logits / get_mask_from_cls_attns, losses.py:121-164."""
+    order = torch.argsort(values, dim=-1, descending=True)
+    nk = int(values.shape[-1] * keep_ratio)
+    mask = torch.cat((torch.ones_like(order[:, :nk]), torch.zeros_like(order[:, nk:])), dim=-1).float()
+    mask.scatter_(index=order, src=mask.clone(), dim=-1)
+    return mask
+
+
+def teacher_target(cls_attn):
+    """losses.py:76-79 - mean over layers, max over heads, drop CLS column, renormalise."""
+    w = torch.mean(cls_attn, dim=1)
+    w, _ = torch.max(w, dim=1)
+    return w[:, 1:] / torch.sum(w[:, 1:], dim=-1, keepdim=True)
+
+
+def mask_loss_kl(pred_logits, cls_attn, kept, keep_ratios):
+    """MaskLoss.forward, kl_div branch, losses.py:75-96.  Returns (loss, [mask_acc_i])."""
+    target = teacher_target(cls_attn)
+    loss = 0
+    accs = []
+    for i in range(len(kept)):
+        if i > 0:
+            ratio = keep_ratios[i] / keep_ratios[i - 1]
+            gt = topk_mask(torch.gather(target, 1, kept[i - 1]), ratio)
+            pm = topk_mask(F.softmax(pred_logits[i], dim=-1), ratio)
+            target = torch.gather(target, 1, kept[i - 1])
+            target = target / torch.sum(target, dim=1, keepdim=True)
+        else:
+            gt = topk_mask(target, keep_ratios[i])
+            pm = topk_mask(F.softmax(pred_logits[i], dim=-1), keep_ratios[i])
+        loss = loss + F.kl_div(F.log_softmax(pred_logits[i], dim=-1), torch.log(target),
+                               log_target=True, reduction="batchmean")
+        accs.append(torch.sum(pm == gt) / pm.numel())
+    return loss, accs
+
+
+def backbone_loss(logits_s, token_s, logits_t, token_t, kept, labels):
+    """BackboneLoss.forward, losses.py:185-227 (mixup off -> CrossEntropyLoss, :174).  The teacher tokens
+    are gathered with the LAST stage's (stage-relative) ids exactly as the reference does (:212).
+    Returns (total, cls_loss, cls_kl, token_kl)."""
+    cls_loss = F.cross_entropy(logits_s, labels)
+    cls_kl = F.kl_div(F.log_softmax(logits_s, dim=-1), F.log_softmax(logits_t, dim=-1),
+                      reduction="batchmean", log_target=True)
+    C = token_t.shape[-1]
+    tt = torch.gather(token_t, 1, kept[-1].unsqueeze(-1).expand(-1, -1, C)).reshape(-1, C)
+    ts = token_s.reshape(-1, C)
+    tok_kl = F.kl_div(F.log_softmax(ts, dim=-1), F.log_softmax(tt, dim=-1), reduction="batchmean",
+                      log_target=True)
+    return cls_loss + cls_kl + tok_kl, cls_loss, cls_kl, tok_kl
+
+
+# --------------------------------------------------------------------------------------------------
+# perturbed top-k
+# --------------------------------------------------------------------------------------------------
+def perturbed_topk_fwd(x, noise, k, sigma):
+    """PerturbedTopKFunction.forward, vit_models/peturbed_topk.py:27-51, with the noise tensor injected.
+    x [b,d], noise [b,nS,d] -> indicators [b,k,d] and the sorted ids [b,nS,k]."""
+    d = x.shape[1]
+    pert = x[:, None, :] + noise * sigma
+    ids = torch.topk(pert, k=k, dim=-1, sorted=False).indices
+    ids = torch.sort(ids, dim=-1).values
+    return F.one_hot(ids, num_classes=d).float().mean(dim=1), ids
+
+
+def perturbed_topk_bwd(grad_out, noise, ids, sigma):
+    """PerturbedTopKFunction.backward, vit_models/peturbed_topk.py:76-79."""
+    d = noise.shape[-1]
+    onehot = F.one_hot(ids, num_classes=d).float()
+    e = torch.einsum("bnkd,bnd->bkd", onehot, noise) / noise.shape[1] / sigma
+    return torch.einsum("bkd,bkd->bd", grad_out, e)
+
+
+# --------------------------------------------------------------------------------------------------
+# the training step (train.py:40-57) with the optimiser of mask_predictor.py / utils.py:67-90
+# --------------------------------------------------------------------------------------------------
+def param_groups(named_params, weight_decay):
+    """utils.get_param_groups, utils.py:67-90.  named_params: iterable of (name, tensor)."""
+    decay, no_decay, pred = [], [], []
+    for name, p in named_params:
+        if "predictor" in name or "dist" in name:
+            pred.append(p)
+        elif not p.requires_grad:
+            continue
+        elif "cls_token" in name or "pos_embed" in name:
+            continue
+        elif p.dim() == 1 or name.endswith(".bias"):
+            no_decay.append(p)
+        else:
+            decay.append(p)
+    return [dict(params=pred, weight_decay=weight_decay, name="predictor"),
+            dict(params=no_decay, weight_decay=0.0, name="base_no_decay"),
+            dict(params=decay, weight_decay=weight_decay, name="base_decay")]
+
+
+def cosine_lrs(step, epochs, lr, min_lr, warmup_steps):
+    """utils.adjust_learning_rate, utils.py:96-122: (predictor_lr, backbone_lr)."""
+    cos_lr = (math.cos(step / epochs * math.pi) + 1) * 0.5
+    cos_lr = min_lr + cos_lr * (lr - min_lr)
+    if step < warmup_steps:
+        return cos_lr, 0.0
+    return cos_lr, min(lr * 0.01, cos_lr)
+
+
+def train_step_losses(sd_s, sd_t, cfg, x, labels, warmup=False):
+    """train.py:40-53: teacher fwd (no grad), student fwd, MaskLoss + BackboneLoss, warm-up switch."""
+    tcfg = dict(cfg)
+    tcfg["pruning_loc"] = ()
+    with torch.no_grad():
+        logits_t, token_t, cls_attn = teacher_forward(sd_t, x.clone(), tcfg)
+    (logits_s, token_s, pred_logits, kept), aux = student_forward(sd_s, x.clone(), cfg, training=True)
+    m_loss, accs = mask_loss_kl(pred_logits, cls_attn, kept, cfg["token_ratio"])
+    b_loss, cls_loss, cls_kl, tok_kl = backbone_loss(logits_s, token_s, logits_t, token_t, kept, labels)
+    total = m_loss if warmup else b_loss + m_loss
+    return total, dict(mask_loss=m_loss, backbone_loss=b_loss, cls_loss=cls_loss, cls_kl=cls_kl,
+                       token_kl=tok_kl, mask_accs=accs, logits_s=logits_s, token_s=token_s,
+                       pred_logits=pred_logits, kept=kept, logits_t=logits_t, token_t=token_t,
+                       cls_attn=cls_attn, aux=aux)
+
+
+class TrainState:
+    """Holds leaf parameter tensors + AdamW exactly as mask_predictor.py:224-232 builds them
+    (AdamW over utils.get_param_groups; cls_token / pos_embed are never optimised, utils.py:79-80)."""
+
+    def __init__(self, sd_student, sd_teacher, cfg, lr=1e-3, min_lr=1e-5, weight_decay=0.05, epochs=30,
+                 warmup_steps=0):
+        self.cfg = cfg
+        self.sd_s = {k: v.clone().requires_grad_(True) for k, v in sd_student.items()}
+        self.sd_t = {k: v.clone() for k, v in sd_teacher.items()}
+        self.lr, self.min_lr, self.epochs, self.warmup_steps = lr, min_lr, epochs, warmup_steps
+        self.groups = param_groups(self.sd_s.items(), weight_decay)
+        self.opt = torch.optim.AdamW([g for g in self.groups if len(g["params"])], lr=lr)
+        self.set_epoch(0)
+
+    def set_epoch(self, step):
+        """utils.adjust_learning_rate: lr per group and requires_grad toggling (utils.py:110-147)."""
+        self.epoch = step
+        pred_lr, bb_lr = cosine_lrs(step, self.epochs, self.lr, self.min_lr, self.warmup_steps)
+        for name, p in self.sd_s.items():
+            is_pred = "predictor" in name or "dist" in name
+            p.requires_grad_(True if is_pred else step >= self.warmup_steps)
+        for g in self.opt.param_groups:
+            g["lr"] = pred_lr if g["name"] == "predictor" else bb_lr
+            for p in g["params"]:
+                p.requires_grad_(g["lr"] != 0)
+
+    def step(self, x, labels):
+        """train.py:40-57."""
+        total, info = train_step_losses(self.sd_s, self.sd_t, self.cfg, x, labels,
+                                        warmup=self.epoch < self.warmup_steps)
+        self.opt.zero_grad()
+        total.backward()
+        self.opt.step()
+        info["loss"] = total.detach()
+        return info
