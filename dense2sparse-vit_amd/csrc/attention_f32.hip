@@ -1,0 +1,371 @@
+// Fused multi-head attention, fp32 on the f32-input MFMA (32x32x2), head dim 64 (every model on the path).
+// Replaces Attention.forward's q@k^T -> softmax -> @v (vit_models/dynamic_vit.py:218-229) without materialising
+// the [B,H,n,n] matrix, emits the CLS row of the softmax that the reference returns (:234) and that the teacher's
+// rows feed into MaskLoss (losses.py:76-79), and provides the backward (dq, dk, dv) by recomputation from the
+// saved log-sum-exp.
+//
+// qkv is the raw output of the qkv Linear: [B, n, 3, H, 64] (row stride 3*H*64); out / dout are [B, n, H*64].
+//
+// Orientation trick (no cross-lane traffic for P): forward and dQ compute S^T = K Q^T, so a lane owns ONE query
+// (column) and 16 of the tile's 32 keys (rows) in its accumulator registers - the row softmax is an in-lane
+// reduction plus one exchange between the half-waves, and the accumulator registers are, as they stand, the
+// A operand of the following P V (resp. dS K) product.  dK/dV use the natural orientation S = Q K^T for the same
+// reason (their sums run over queries).
+//
+// MFMA maps (d2s_common.h): lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; C reg r: row (r&3)+8(r>>2)+4(l>>5),
+// col l&31.  The 64-long d reduction is walked as 32 steps; step s = 4t+j uses d = 8t + 4*half + j, so each lane
+// fetches its operand as 8 float4 (t = 0..7).
+#include "d2s_common.h"
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int PITCH = 68;  // floats; 16-B aligned rows, conflict-free ds_read_b128 for 16 distinct rows
+
+__device__ __forceinline__ void load_rows_regs(const float* __restrict__ base, long ld, int row, int nrows, int half,
+                                               float scale, f32x4 (&r)[8]) {
+    // operand fragment of one token row for lane (row, half): r[t] = base[row][8t + 4half .. +3] * scale
+    if (row < nrows) {
+        const float* p = base + (long)row * ld + 4 * half;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            r[t] = *reinterpret_cast<const f32x4*>(p + 8 * t);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[t][j] *= scale;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// cooperative load of a 32-row x 64-float tile (rows row0.., zero-filled beyond nrows) by 256 threads: 2 float4 each
+__device__ __forceinline__ void tile_load(const float* __restrict__ base, long ld, int row0, int nrows, int tid, f32x4 (&r)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + i * 256, row = row0 + (f >> 4), d4 = (f & 15) * 4;
+        r[i] = row < nrows ? *reinterpret_cast<const f32x4*>(base + (long)row * ld + d4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+__device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const f32x4 (&r)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + i * 256;
+        *reinterpret_cast<f32x4*>(&S[(f >> 4) * PITCH + (f & 15) * 4]) = r[i];
+    }
+}
+
+// acc[r] += sum_d X[rowlane][d] * Yreg[d]  : A operand from an LDS tile (row = lane&31), B operand from registers
+__device__ __forceinline__ void mma_lds_reg(const float* __restrict__ S, int l31, int half, const f32x4 (&y)[8], f32x16& acc) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&S[l31 * PITCH + 8 * t + 4 * half]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = mfma32(a[j], y[t][j], acc);
+    }
+}
+// out[dt] += X^T-style product: A operand = accumulator-layout registers p[r], B operand = LDS tile row mfma32_row(r,half)
+__device__ __forceinline__ void mma_reg_lds(const f32x16& p, const float* __restrict__ S, int l31, int half, f32x16 (&o)[2]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float* row = &S[mfma32_row(r, half) * PITCH];
+        o[0] = mfma32(p[r], row[l31], o[0]);
+        o[1] = mfma32(p[r], row[32 + l31], o[1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                       float* __restrict__ lse, float* __restrict__ cls_row, int n, int H,
+                                                       float scale) {
+    __shared__ __attribute__((aligned(16))) float Ks[32 * PITCH];
+    __shared__ __attribute__((aligned(16))) float Vs[32 * PITCH];
+    extern __shared__ __attribute__((aligned(16))) float cls_s[];  // [n] raw scaled scores of query 0 (block 0 only)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const long ld = 3L * H * DH;
+    const float* qb = qkv + (long)b * n * ld + h * DH;
+    const float* kb = qb + (long)H * DH;
+    const float* vb = kb + (long)H * DH;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bool active = q0 < n;
+    const bool want_cls = cls_row != nullptr && blockIdx.x == 0 && wave == 0;
+
+    f32x4 qreg[8];
+    load_rows_regs(qb, ld, q0 + l31, n, half, scale, qreg);
+
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (n + 31) / 32;
+    f32x4 kr[2], vr[2];
+    tile_load(kb, ld, 0, n, tid, kr);
+    tile_load(vb, ld, 0, n, tid, vr);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        tile_store(Ks, tid, kr);
+        tile_store(Vs, tid, vr);
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            tile_load(kb, ld, (t + 1) * 32, n, tid, kr);
+            tile_load(vb, ld, (t + 1) * 32, n, tid, vr);
+        }
+        if (!active) continue;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        mma_lds_reg(Ks, l31, half, qreg, s);  // s[r] = S^T[key = row(r,half)][query = l31], already scaled
+        const int kv0 = t * 32;
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (kv0 + mfma32_row(r, half) >= n) s[r] = -INFINITY;
+            mt = fmaxf(mt, s[r]);
+        }
+        if (want_cls && l31 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + mfma32_row(r, half);
+                if (key < n) cls_s[key] = s[r];
+            }
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __expf(m_run - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __expf(s[r] - m_new);
+            rs += s[r];
+        }
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+        // rescale O: row (query) of O register r in this lane is row(r,half); its alpha lives in lane row(r,half)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a = __shfl(alpha, mfma32_row(r, half), 64);
+            o[0][r] *= a;
+            o[1][r] *= a;
+        }
+        mma_reg_lds(s, Vs, l31, half, o);
+    }
+    if (!active) return;
+    const float inv_l = 1.0f / l_run;
+    float* ob = out + (long)b * n * H * DH + h * DH;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qi = mfma32_row(r, half);
+        const float il = __shfl(inv_l, qi, 64);
+        if (q0 + qi < n) {
+            float* p = ob + (long)(q0 + qi) * H * DH;
+            p[l31] = o[0][r] * il;
+            p[32 + l31] = o[1][r] * il;
+        }
+    }
+    if (half == 0 && q0 + l31 < n) lse[((long)b * H + h) * n + q0 + l31] = m_run + logf(l_run);
+    if (want_cls) {
+        const float m0 = __shfl(m_run, 0, 64), il0 = __shfl(inv_l, 0, 64);
+        float* cr = cls_row + ((long)b * H + h) * n;
+        // cls_s was written by lanes 0 and 32 of this wave only; same-wave LDS accesses are ordered
+        for (int j = lane; j < n; j += 64) cr[j] = expf(cls_s[j] - m0) * il0;
+    }
+}
+
+// delta[b,h,i] = sum_d dout[b,i,h,d] * out[b,i,h,d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ out, const float* __restrict__ dout,
+                                                         float* __restrict__ delta, long rows, int n, int H) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long b = row / n, i = row - b * n;
+    for (int h = 0; h < H; ++h) {
+        const long e = row * H * DH + h * DH + lane;
+        const float s = wave_sum(out[e] * dout[e]);
+        if (lane == 0) delta[(b * H + h) * n + i] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward, dQ: one wave per 32 queries, loops over key tiles (same orientation as forward)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          float* __restrict__ dqkv, int n, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) float Ks[32 * PITCH];
+    __shared__ __attribute__((aligned(16))) float Vs[32 * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const long ld = 3L * H * DH, ldo = (long)H * DH;
+    const float* qb = qkv + (long)b * n * ld + h * DH;
+    const float* kb = qb + (long)H * DH;
+    const float* vb = kb + (long)H * DH;
+    const float* dob = dout + (long)b * n * ldo + h * DH;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bool active = q0 < n;
+
+    f32x4 qreg[8], doreg[8];
+    load_rows_regs(qb, ld, q0 + l31, n, half, scale, qreg);
+    load_rows_regs(dob, ldo, q0 + l31, n, half, 1.0f, doreg);
+    const bool qok = q0 + l31 < n;
+    const float lse_i = qok ? lse[((long)b * H + h) * n + q0 + l31] : INFINITY;
+    const float dl_i = qok ? delta[((long)b * H + h) * n + q0 + l31] : 0.f;
+
+    f32x16 dq[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+
+    const int ntiles = (n + 31) / 32;
+    f32x4 kr[2], vr[2];
+    tile_load(kb, ld, 0, n, tid, kr);
+    tile_load(vb, ld, 0, n, tid, vr);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        tile_store(Ks, tid, kr);
+        tile_store(Vs, tid, vr);
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            tile_load(kb, ld, (t + 1) * 32, n, tid, kr);
+            tile_load(vb, ld, (t + 1) * 32, n, tid, vr);
+        }
+        if (!active) continue;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        mma_lds_reg(Ks, l31, half, qreg, s);    // scaled scores^T
+        mma_lds_reg(Vs, l31, half, doreg, dp);  // dP^T[key][query] = sum_d V[key][d] dO[query][d]
+        const int kv0 = t * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = (kv0 + mfma32_row(r, half) < n) ? __expf(s[r] - lse_i) : 0.f;
+            s[r] = p * (dp[r] - dl_i);          // dS^T
+        }
+        mma_reg_lds(s, Ks, l31, half, dq);      // dQ[query][d] += sum_key dS^T[key][query] K[key][d]
+    }
+    if (!active) return;
+    float* dqb = dqkv + (long)b * n * ld + h * DH;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qi = q0 + mfma32_row(r, half);
+        if (qi < n) {
+            float* p = dqb + (long)qi * ld;
+            p[l31] = dq[0][r] * scale;
+            p[32 + l31] = dq[1][r] * scale;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward, dK / dV: one wave per 32 keys, loops over query tiles (natural orientation S = Q K^T)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           float* __restrict__ dqkv, int n, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) float Qs[32 * PITCH];
+    __shared__ __attribute__((aligned(16))) float Ds[32 * PITCH];
+    __shared__ float lse_s[32], dl_s[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const long ld = 3L * H * DH, ldo = (long)H * DH;
+    const float* qb = qkv + (long)b * n * ld + h * DH;
+    const float* kb = qb + (long)H * DH;
+    const float* vb = kb + (long)H * DH;
+    const float* dob = dout + (long)b * n * ldo + h * DH;
+    const float* lse_b = lse + ((long)b * H + h) * n;
+    const float* dl_b = delta + ((long)b * H + h) * n;
+    const int k0 = blockIdx.x * 128 + wave * 32;
+    const bool active = k0 < n;
+
+    f32x4 kreg[8], vreg[8];
+    load_rows_regs(kb, ld, k0 + l31, n, half, scale, kreg);  // scaled copy, used for the scores only
+    load_rows_regs(vb, ld, k0 + l31, n, half, 1.0f, vreg);
+
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+
+    const int ntiles = (n + 31) / 32;
+    f32x4 qr[2], dr[2];
+    float lr = 0.f, dlr = 0.f;
+    tile_load(qb, ld, 0, n, tid, qr);
+    tile_load(dob, ldo, 0, n, tid, dr);
+    if (tid < 32) { lr = tid < n ? lse_b[tid] : INFINITY; dlr = tid < n ? dl_b[tid] : 0.f; }
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        tile_store(Qs, tid, qr);
+        tile_store(Ds, tid, dr);
+        if (tid < 32) { lse_s[tid] = lr; dl_s[tid] = dlr; }
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            tile_load(qb, ld, (t + 1) * 32, n, tid, qr);
+            tile_load(dob, ldo, (t + 1) * 32, n, tid, dr);
+            if (tid < 32) {
+                const int qi = (t + 1) * 32 + tid;
+                lr = qi < n ? lse_b[qi] : INFINITY;
+                dlr = qi < n ? dl_b[qi] : 0.f;
+            }
+        }
+        if (!active) continue;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        mma_lds_reg(Qs, l31, half, kreg, s);   // S[query = row(r,half)][key = l31], scaled
+        mma_lds_reg(Ds, l31, half, vreg, dp);  // dP[query][key] = sum_d dO[query][d] V[key][d]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = mfma32_row(r, half);
+            const float p = __expf(s[r] - lse_s[qi]);  // rows beyond n carry lse = +inf -> p = 0
+            s[r] = p;
+            dp[r] = p * (dp[r] - dl_s[qi]);
+        }
+        mma_reg_lds(s, Ds, l31, half, dv);     // dV[key][d] += sum_query P[query][key] dO[query][d]
+        mma_reg_lds(dp, Qs, l31, half, dk);    // dK[key][d] += sum_query dS[query][key] Q[query][d]
+    }
+    if (!active) return;
+    float* dkb = dqkv + (long)b * n * ld + (long)H * DH + h * DH;
+    float* dvb = dkb + (long)H * DH;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ki = k0 + mfma32_row(r, half);
+        if (ki < n) {
+            float* pk = dkb + (long)ki * ld;
+            float* pv = dvb + (long)ki * ld;
+            pk[l31] = dk[0][r] * scale;
+            pk[32 + l31] = dk[1][r] * scale;
+            pv[l31] = dv[0][r];
+            pv[32 + l31] = dv[1][r];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// qkv [B,n,3,H,64] -> out [B,n,H*64], lse [B,H,n]; cls_row [B,H,n] (softmax row of query 0) if non-null.
+int d2s_attn_fwd_f32(const float* qkv, float* out, float* lse, float* cls_row, int B, int n, int H, float scale,
+                     hipStream_t stream) {
+    if (!qkv || !out || !lse || B <= 0 || n <= 0 || H <= 0 || n > 8192) return D2S_ERR_ARG;
+    dim3 grid((n + 127) / 128, B * H), block(256);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, block, cls_row ? (size_t)n * sizeof(float) : 0, stream, qkv, out, lse, cls_row, n, H,
+                       scale);
+    return d2s_check_launch();
+}
+
+// dqkv [B,n,3,H,64] is fully written.  delta_ws: [B,H,n] floats of scratch.
+int d2s_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws, int B,
+                     int n, int H, float scale, hipStream_t stream) {
+    if (!qkv || !out || !dout || !lse || !dqkv || !delta_ws || B <= 0 || n <= 0 || H <= 0) return D2S_ERR_ARG;
+    const long rows = (long)B * n;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, out, dout, delta_ws, rows, n, H);
+    dim3 grid((n + 127) / 128, B * H), block(256);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, n, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, n, H, scale);
+    return d2s_check_launch();
+}
+
+}  // extern "C"

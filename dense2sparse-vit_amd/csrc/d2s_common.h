@@ -1,0 +1,52 @@
+// Shared device helpers for the d2s HIP library (gfx950 / CDNA4 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define D2S_OK 0
+#define D2S_ERR_ARG (-1)       // bad shape / null pointer / unsupported size
+#define D2S_ERR_WORKSPACE (-2) // workspace too small
+#define D2S_ERR_LAUNCH (-3)    // hipGetLastError() after launch
+
+#define D2S_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int d2s_check_launch() { return hipGetLastError() == hipSuccess ? D2S_OK : D2S_ERR_LAUNCH; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// sum over the 32 lanes of each half-wave (lanes 0-31 / 32-63 separately)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// 32x32x2 f32 MFMA.  Lane l: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
+// C/D register r of lane l: row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31.
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma32_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}

@@ -1,0 +1,350 @@
+// fp32 GEMM on the gfx950 f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact f32, k-ordered fma
+// chain).  Replaces the nn.Linear / Conv2d-as-GEMM calls of the reference's hot path
+// (vit_models/dynamic_vit.py:169-175 Mlp, :218,231 qkv/proj, :298 patch conv, :491-531 predictor,
+// :1006 head) and their autograd backward (dgrad / wgrad).
+//
+//   C[M,N] = op(A) * op(B)   with reduction length K
+//     ALAY 0: A stored [M][K] (k contiguous)      ALAY 1: A stored [K][M] (m contiguous)
+//     BLAY 0: B stored [N][K] (k contiguous)      BLAY 1: B stored [K][N] (n contiguous)
+//   forward  y = x W^T      : ALAY0, BLAY0  ("NT")
+//   dgrad    dx = dy W      : ALAY0, BLAY1  ("NN")
+//   wgrad    dW = dy^T x    : ALAY1, BLAY1  ("TN"), reduction over the B*n token rows, split-K slabs
+//
+// Tile 128x128x16, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of 32x32 (64 accumulator
+// VGPRs).  LDS image is [k][row] with the row index XOR-swizzled by ((k>>2)&3)<<3, which makes both the
+// transposing ds_write_b32 of k-contiguous operands and the ds_read_b32 fragment reads conflict-free.
+// Global->register prefetch of tile t+1 is issued before the 32 MFMAs of tile t; one barrier per K-step.
+#include "d2s_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+
+enum Epi : int {
+    EPI_NONE = 0,
+    EPI_BIAS = 1,          // C = acc + bias[n]
+    EPI_BIAS_RELU = 2,     // C = relu(acc + bias[n])
+    EPI_BIAS_GELU = 3,     // aux_out = acc + bias[n] (pre-activation, if given); C = gelu(.)
+    EPI_BIAS_RESID = 4,    // C = acc + bias[n] + aux[m][n]
+    EPI_MUL_GELU_GRAD = 5, // C = acc * gelu'(aux[m][n])      (aux = saved pre-activation)
+    EPI_MUL_RELU_MASK = 6, // C = acc * (aux[m][n] > 0)       (aux = saved ReLU output)
+    EPI_BIAS_ROWADD = 7,   // C = acc + bias[n] + aux[(m % aux_rows)][n]  (patch embed: + pos_embed rows)
+    EPI_ACCUM = 8,         // C += acc
+};
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* aux; float* aux_out;
+    long lda, ldb, ldc, ldaux;
+    int M, N, K;
+    int epi;
+    int k_per_slice;   // reduction elements per blockIdx.z slice (multiple of BK)
+    long slab_stride;  // elements between split-K slabs (0 when gridDim.z == 1)
+    int aux_rows;      // EPI_BIAS_ROWADD
+    int vecA, vecB;    // 16-byte vector loads allowed for A / B
+    // output row remap (patch embed writes token t of image b to row b*(T+1)+1+t): out_row = m + m / rows_per_img * skip + skip0
+    int remap_rows_per_img; int remap_skip;
+};
+
+template <int LAY>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, int row0, int k0, int rows, int kend,
+                                          int vec, int tid, f32x4 (&r)[2]) {
+    // rows = valid extent of the row dimension, kend = valid extent of the reduction dimension
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + i * 256;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (LAY == 0) {
+            const int row = row0 + (f >> 2), k = k0 + (f & 3) * 4;
+            if (row < rows) {
+                const float* p = P + (long)row * ld + k;
+                if (vec && k + 3 < kend) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+                    if (k + 0 < kend) v[0] = p[0];
+                    if (k + 1 < kend) v[1] = p[1];
+                    if (k + 2 < kend) v[2] = p[2];
+                    if (k + 3 < kend) v[3] = p[3];
+                }
+            }
+        } else {
+            const int k = k0 + (f >> 5), row = row0 + (f & 31) * 4;
+            if (k < kend) {
+                const float* p = P + (long)k * ld + row;
+                if (vec && row + 3 < rows) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+                    if (row + 0 < rows) v[0] = p[0];
+                    if (row + 1 < rows) v[1] = p[1];
+                    if (row + 2 < rows) v[2] = p[2];
+                    if (row + 3 < rows) v[3] = p[3];
+                }
+            }
+        }
+        r[i] = v;
+    }
+}
+
+template <int LAY>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const f32x4 (&r)[2]) {
+    // S: [BK][128] floats, element (k,row) at k*128 + (row ^ (((k>>2)&3)<<3))
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + i * 256;
+        if (LAY == 0) {
+            const int row = f >> 2, kq = f & 3;
+            const int col = row ^ (kq << 3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) S[(kq * 4 + j) * 128 + col] = r[i][j];
+        } else {
+            const int k = f >> 5, row = (f & 31) * 4;
+            const int col = row ^ (((k >> 2) & 3) << 3);
+            *reinterpret_cast<f32x4*>(&S[k * 128 + col]) = r[i];
+        }
+    }
+}
+
+template <int ALAY, int BLAY>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * 128];
+    float* As = smem;                  // [2][BK][128]
+    float* Bs = smem + 2 * BK * 128;   // [2][BK][128]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order: consecutive workgroups (same XCD every 8) walk along N for one M panel so that the
+    // A panel (activations) is shared through one L2.  Bijective remap for any grid size.
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / nbn, bn = bid % nbn;
+    const int row0 = bm * BM, col0 = bn * BN;
+
+    const int kbeg = blockIdx.z * p.k_per_slice;
+    const int kend = min(p.K, kbeg + p.k_per_slice);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[2], rb[2];
+    if (nk > 0) {
+        load_tile<ALAY>(p.A, p.lda, row0, kbeg, p.M, kend, p.vecA, tid, ra);
+        load_tile<BLAY>(p.B, p.ldb, col0, kbeg, p.N, kend, p.vecB, tid, rb);
+        store_tile<ALAY>(As, tid, ra);
+        store_tile<BLAY>(Bs, tid, rb);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            load_tile<ALAY>(p.A, p.lda, row0, kbeg + (kt + 1) * BK, p.M, kend, p.vecA, tid, ra);
+            load_tile<BLAY>(p.B, p.ldb, col0, kbeg + (kt + 1) * BK, p.N, kend, p.vecB, tid, rb);
+        }
+        const float* Ac = As + cur * BK * 128;
+        const float* Bc = Bs + cur * BK * 128;
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            const int k = 2 * s + half;
+            const int sw = ((k >> 2) & 3) << 3;
+            const float a0 = Ac[k * 128 + ((wm * 64 + l31) ^ sw)];
+            const float a1 = Ac[k * 128 + ((wm * 64 + 32 + l31) ^ sw)];
+            const float b0 = Bc[k * 128 + ((wn * 64 + l31) ^ sw)];
+            const float b1 = Bc[k * 128 + ((wn * 64 + 32 + l31) ^ sw)];
+            acc[0][0] = mfma32(a0, b0, acc[0][0]);
+            acc[0][1] = mfma32(a0, b1, acc[0][1]);
+            acc[1][0] = mfma32(a1, b0, acc[1][0]);
+            acc[1][1] = mfma32(a1, b1, acc[1][1]);
+        }
+        if (kt + 1 < nk) {
+            store_tile<ALAY>(As + (cur ^ 1) * BK * 128, tid, ra);
+            store_tile<BLAY>(Bs + (cur ^ 1) * BK * 128, tid, rb);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    float* Cb = p.C + (long)blockIdx.z * p.slab_stride;
+    const int epi = (gridDim.z > 1) ? (int)EPI_NONE : p.epi;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = col0 + wn * 64 + nt * 32 + l31;
+            if (n >= p.N) continue;
+            float bias = 0.f;
+            if (epi == EPI_BIAS || epi == EPI_BIAS_RELU || epi == EPI_BIAS_GELU || epi == EPI_BIAS_RESID ||
+                epi == EPI_BIAS_ROWADD)
+                bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = row0 + wm * 64 + mt * 32 + mfma32_row(r, half);
+                if (m >= p.M) continue;
+                float v = acc[mt][nt][r];
+                long orow = m;
+                if (p.remap_rows_per_img > 0) orow = (long)m + (long)(m / p.remap_rows_per_img) * p.remap_skip + p.remap_skip;
+                float* cp = Cb + orow * p.ldc + n;
+                switch (epi) {
+                    case EPI_BIAS: v += bias; break;
+                    case EPI_BIAS_RELU: v = fmaxf(v + bias, 0.f); break;
+                    case EPI_BIAS_GELU:
+                        v += bias;
+                        if (p.aux_out) p.aux_out[(long)m * p.ldc + n] = v;
+                        v = gelu_erf(v);
+                        break;
+                    case EPI_BIAS_RESID: v += bias + p.aux[(long)m * p.ldaux + n]; break;
+                    case EPI_MUL_GELU_GRAD: v *= gelu_erf_grad(p.aux[(long)m * p.ldaux + n]); break;
+                    case EPI_MUL_RELU_MASK: v = p.aux[(long)m * p.ldaux + n] > 0.f ? v : 0.f; break;
+                    case EPI_BIAS_ROWADD: v += bias + p.aux[(long)(m % p.aux_rows) * p.ldaux + n]; break;
+                    case EPI_ACCUM: v += *cp; break;
+                    default: break;
+                }
+                *cp = v;
+            }
+        }
+    }
+}
+
+// Deterministic split-K combine: C (+)= sum over slabs in slab order.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C,
+                                                            long ldc, int M, int N, int slabs, long slab_stride,
+                                                            int accumulate) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)M * N;
+    if (idx >= total) return;
+    const int m = (int)(idx / N), n = (int)(idx % N);
+    float s = 0.f;
+    for (int z = 0; z < slabs; ++z) s += ws[(long)z * slab_stride + (long)m * N + n];
+    float* cp = C + (long)m * ldc + n;
+    *cp = accumulate ? (*cp + s) : s;
+}
+
+// Column sums (bias gradients): out[n] (+)= sum_m X[m][n].  Stage 1: each block owns 64 columns and a row slice.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long ldx, int M, int N,
+                                                             int rows_per_slice, float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const int m0 = blockIdx.y * rows_per_slice, m1 = min(M, m0 + rows_per_slice);
+    float s = 0.f;
+    if (n < N)
+        for (int m = m0 + wave; m < m1; m += 4) s += X[(long)m * ldx + n];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && n < N) part[(long)blockIdx.y * N + n] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int N, int slices,
+                                                           float* __restrict__ out, int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int z = 0; z < slices; ++z) s += part[(long)z * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+// Workspace needed by d2s_gemm_f32 for a given problem (only the TN / wgrad layout splits K).
+size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K) {
+    if (layout != 2) return 0;
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int slices = (1024 + tiles - 1) / tiles;
+    const int max_slices = (K + 255) / 256;
+    if (slices > max_slices) slices = max_slices;
+    if (slices <= 1) return 0;
+    return (size_t)slices * M * N * sizeof(float);
+}
+
+// layout 0 = NT (A[M,K], B[N,K]); 1 = NN (A[M,K], B[K,N]); 2 = TN (A[K,M], B[K,N]).
+// epilogue: see enum Epi.  accumulate != 0 (TN only): C += result.  remap_*: see GemmArgs.
+int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                 int K, int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, int aux_rows,
+                 int remap_rows_per_img, int remap_skip, int accumulate, void* workspace, size_t workspace_bytes,
+                 hipStream_t stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || layout < 0 || layout > 2) return D2S_ERR_ARG;
+    if ((epilogue == EPI_BIAS_RESID || epilogue == EPI_MUL_GELU_GRAD || epilogue == EPI_MUL_RELU_MASK ||
+         epilogue == EPI_BIAS_ROWADD) && !aux)
+        return D2S_ERR_ARG;
+    GemmArgs p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux = aux; p.aux_out = aux_out;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
+    p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.aux_rows = aux_rows > 0 ? aux_rows : 1;
+    p.remap_rows_per_img = remap_rows_per_img; p.remap_skip = remap_skip;
+    const int alay = layout == 2 ? 1 : 0, blay = layout == 0 ? 0 : 1;
+    p.vecA = aligned16(A) && (lda % 4 == 0) && (alay == 0 ? (K % 4 == 0) : (M % 4 == 0));
+    p.vecB = aligned16(B) && (ldb % 4 == 0) && (blay == 0 ? (K % 4 == 0) : (N % 4 == 0));
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int slices = 1;
+    if (layout == 2) {
+        slices = (1024 + tiles - 1) / tiles;
+        const int max_slices = (K + 255) / 256;
+        if (slices > max_slices) slices = max_slices;
+        if (slices < 1) slices = 1;
+    }
+    int kper = (K + slices - 1) / slices;
+    kper = ((kper + BK - 1) / BK) * BK;
+    slices = (K + kper - 1) / kper;
+    p.k_per_slice = kper;
+    p.slab_stride = 0;
+    float* realC = C;
+    if (slices > 1) {
+        const size_t need = (size_t)slices * M * N * sizeof(float);
+        if (!workspace || workspace_bytes < need) return D2S_ERR_WORKSPACE;
+        p.C = static_cast<float*>(workspace);
+        p.ldc = N;
+        p.slab_stride = (long)M * N;
+        p.remap_rows_per_img = 0;
+    } else if (accumulate) {
+        p.epi = EPI_ACCUM;
+    }
+    dim3 grid(tiles, 1, slices), block(256);
+    if (layout == 0) hipLaunchKernelGGL((gemm_f32_kernel<0, 0>), grid, block, 0, stream, p);
+    else if (layout == 1) hipLaunchKernelGGL((gemm_f32_kernel<0, 1>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), grid, block, 0, stream, p);
+    if (slices > 1) {
+        const long total = (long)M * N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), block, 0, stream,
+                           static_cast<const float*>(workspace), realC, ldc, M, N, slices, (long)M * N, accumulate);
+    }
+    return d2s_check_launch();
+}
+
+size_t d2s_colsum_workspace_bytes(int M, int N) {
+    int slices = (M + 511) / 512;
+    if (slices > 128) slices = 128;
+    if (slices < 1) slices = 1;
+    return (size_t)slices * N * sizeof(float);
+}
+
+// out[n] (+)= sum_m X[m][n]  - bias gradients of every Linear on the path.
+int d2s_colsum_f32(const float* X, long ldx, int M, int N, float* out, int accumulate, void* workspace,
+                   size_t workspace_bytes, hipStream_t stream) {
+    if (!X || !out || M <= 0 || N <= 0) return D2S_ERR_ARG;
+    int slices = (M + 511) / 512;
+    if (slices > 128) slices = 128;
+    if (slices < 1) slices = 1;
+    const int rps = (M + slices - 1) / slices;
+    slices = (M + rps - 1) / rps;
+    if (!workspace || workspace_bytes < (size_t)slices * N * sizeof(float)) return D2S_ERR_WORKSPACE;
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, slices), dim3(256), 0, stream, X, ldx, M, N, rps, part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, slices, out, accumulate);
+    return d2s_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,258 @@
+// LayerNorm forward / backward, one wave per token row, row cached in registers (float4 per lane).
+// Replaces nn.LayerNorm in Block (vit_models/dynamic_vit.py:245,250,266,268; eps 1e-6 at :678), the final norm
+// (:993) and the predictor's LayerNorms (:491-531, default eps 1e-5).  HBM-bound: one read + one write per
+// element in forward; backward reads x and dy once, writes dx once, and produces deterministic per-block
+// partial sums for dweight / dbias that a second tiny kernel folds.
+//
+// Rows may be addressed through a RowMap so that the predictor can read x[:, 1:] of a [B, n, D] buffer in place
+// (dynamic_vit.py:855) and its backward can add into rows 1.. of the gradient buffer.
+#include "d2s_common.h"
+
+namespace {
+
+struct RowMap {  // logical row r -> element offset
+    long rows_per_group, group_stride, row_stride, offset;
+};
+__device__ __forceinline__ long map_row(const RowMap& m, long r) {
+    const long g = r / m.rows_per_group, t = r - g * m.rows_per_group;
+    return g * m.group_stride + m.offset + t * m.row_stride;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, RowMap xm, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     long rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + map_row(xm, row);
+    const int nvec = D >> 2;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + c * 4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        } else {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[i][j] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    float* yr = y + row * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c * 4);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(b + c * 4);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * wv[j] + bv[j];
+            *reinterpret_cast<f32x4*>(yr + c * 4) = o;
+        }
+    }
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+}
+
+// Backward.  Each block owns a contiguous chunk of rows; every wave walks its share and accumulates dweight /
+// dbias in registers; partials land in part[block][2][D].
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, RowMap xm, const float* __restrict__ dy,
+                                                     const float* __restrict__ w, const float* __restrict__ mean_in,
+                                                     const float* __restrict__ rstd_in, float* __restrict__ dx, RowMap dxm,
+                                                     const float* __restrict__ add_src, float* __restrict__ part,
+                                                     long rows, int D, long rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [3][2][D]  (waves 1..3)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nvec = D >> 2;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    f32x4 wv[NV], dw[NV], db[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        wv[i] = c < nvec ? *reinterpret_cast<const f32x4*>(w + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        dw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (long row = r0 + wave; row < r1; row += 4) {
+        const float* xr = x + map_row(xm, row);
+        const float* gr = dy + row * D;
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        f32x4 xh[NV], g[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nvec) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c * 4);
+                g[i] = *reinterpret_cast<const f32x4*>(gr + c * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xh[i][j] = (xv[j] - mean) * rstd;
+                    const float gw = g[i][j] * wv[i][j];
+                    s1 += gw;
+                    s2 += gw * xh[i][j];
+                    dw[i][j] += g[i][j] * xh[i][j];
+                    db[i][j] += g[i][j];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+        const long doff = map_row(dxm, row);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nvec) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] * wv[i][j] - s1 - xh[i][j] * s2);
+                if (add_src) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(add_src + doff + c * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += a[j];
+                }
+                *reinterpret_cast<f32x4*>(dx + doff + c * 4) = o;
+            }
+        }
+    }
+    if (!part) return;
+    // cross-wave fold: waves 1..3 park their sums in LDS, wave 0 adds them in fixed order
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nvec) {
+                *reinterpret_cast<f32x4*>(&red[((wave - 1) * 2 + 0) * D + c * 4]) = dw[i];
+                *reinterpret_cast<f32x4*>(&red[((wave - 1) * 2 + 1) * D + c * 4]) = db[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* pw = part + (long)blockIdx.x * 2 * D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nvec) {
+                f32x4 a = dw[i], bb = db[i];
+                for (int k = 0; k < 3; ++k) {
+                    const f32x4 t0 = *reinterpret_cast<const f32x4*>(&red[(k * 2 + 0) * D + c * 4]);
+                    const f32x4 t1 = *reinterpret_cast<const f32x4*>(&red[(k * 2 + 1) * D + c * 4]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { a[j] += t0[j]; bb[j] += t1[j]; }
+                }
+                *reinterpret_cast<f32x4*>(pw + c * 4) = a;
+                *reinterpret_cast<f32x4*>(pw + D + c * 4) = bb;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* __restrict__ part, int nblocks, int D,
+                                                          float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 2 * D) return;
+    float s = 0.f;
+    for (int k = 0; k < nblocks; ++k) s += part[(long)k * 2 * D + c];
+    float* o = c < D ? dw + c : db + (c - D);
+    *o = accumulate ? *o + s : s;
+}
+
+inline int pick_nv(int D) {
+    const int nvec = D / 4;
+    if (nvec <= 64) return 1;
+    if (nvec <= 128) return 2;
+    if (nvec <= 256) return 4;
+    if (nvec <= 512) return 8;
+    return 16;
+}
+inline int bwd_blocks(long rows) {
+    long nb = (rows + 31) / 32;
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Row addressing for x (and dx in backward): element offset of logical row r is
+//   (r / rows_per_group) * group_stride + offset + (r % rows_per_group) * row_stride.
+// Contiguous [rows, D]: rows_per_group = rows, group_stride = 0, row_stride = D, offset = 0.
+int d2s_layernorm_fwd(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* w,
+                      const float* b, float* y, float* mean, float* rstd, long rows, int D, float eps, hipStream_t stream) {
+    if (!x || !w || !b || !y || rows <= 0 || D <= 0 || (D & 3) || D > 4096 || rows_per_group <= 0) return D2S_ERR_ARG;
+    if ((group_stride | row_stride | offset) & 3) return D2S_ERR_ARG;
+    RowMap m{rows_per_group, group_stride, row_stride, offset};
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    switch (pick_nv(D)) {
+        case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, stream, x, m, w, b, y, mean, rstd, rows, D, eps); break;
+        case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, x, m, w, b, y, mean, rstd, rows, D, eps); break;
+        case 4: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, stream, x, m, w, b, y, mean, rstd, rows, D, eps); break;
+        case 8: hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, stream, x, m, w, b, y, mean, rstd, rows, D, eps); break;
+        default: hipLaunchKernelGGL(ln_fwd_kernel<16>, grid, block, 0, stream, x, m, w, b, y, mean, rstd, rows, D, eps); break;
+    }
+    return d2s_check_launch();
+}
+
+size_t d2s_layernorm_bwd_workspace_bytes(long rows, int D) { return (size_t)bwd_blocks(rows) * 2 * D * sizeof(float); }
+
+// dx[map(r)] = (add_src ? add_src[map(r)] : 0) + dLN/dx ; dweight / dbias (+)= column sums (skipped if dweight null).
+// x and dx/add_src share one RowMap; dy, mean, rstd are contiguous per logical row.
+int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* dy,
+                      const float* w, const float* mean, const float* rstd, float* dx, const float* add_src, float* dweight,
+                      float* dbias, int accumulate_wb, long rows, int D, void* workspace, size_t workspace_bytes,
+                      hipStream_t stream) {
+    if (!x || !dy || !w || !mean || !rstd || !dx || rows <= 0 || D <= 0 || (D & 3) || D > 4096) return D2S_ERR_ARG;
+    if ((group_stride | row_stride | offset) & 3) return D2S_ERR_ARG;
+    const int nb = bwd_blocks(rows);
+    float* part = nullptr;
+    if (dweight) {
+        if (!dbias) return D2S_ERR_ARG;
+        if (!workspace || workspace_bytes < (size_t)nb * 2 * D * sizeof(float)) return D2S_ERR_WORKSPACE;
+        part = static_cast<float*>(workspace);
+    }
+    RowMap m{rows_per_group, group_stride, row_stride, offset};
+    const long rpb = (rows + nb - 1) / nb;
+    const int nblocks = (int)((rows + rpb - 1) / rpb);
+    dim3 grid(nblocks), block(256);
+    const size_t sh = (size_t)3 * 2 * D * sizeof(float);
+#define D2S_LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, sh, stream, x, m, dy, w, mean, rstd, dx, m, add_src, part, rows, D, rpb)
+    switch (pick_nv(D)) {
+        case 1: D2S_LN_BWD(1); break;
+        case 2: D2S_LN_BWD(2); break;
+        case 4: D2S_LN_BWD(4); break;
+        case 8: D2S_LN_BWD(8); break;
+        default: D2S_LN_BWD(16); break;
+    }
+#undef D2S_LN_BWD
+    if (dweight)
+        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * D + 255) / 256), block, 0, stream, part, nblocks, D, dweight, dbias,
+                           accumulate_wb);
+    return d2s_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+"""ctypes binding of lib/libd2s_hip.so (the C ABI declared in include/d2s_hip.h).
+
+There is no fallback: if the shared object is missing or a symbol cannot be resolved this raises, and every op
+raises on a non-zero return code.  Tensors are passed as raw device pointers; the caller keeps them alive and all
+work is enqueued on torch's current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libd2s_hip.so")
+
+P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, [argtypes]); the trailing hipStream_t is appended automatically for int-returning entries
+_SIGS = {
+    "d2s_gemm_f32_workspace_bytes": (Z, [I, I, I, I]),
+    "d2s_gemm_f32": (I, [I, P, L, P, L, P, L, I, I, I, I, P, P, L, P, I, I, I, I, P, Z]),
+    "d2s_colsum_workspace_bytes": (Z, [I, I]),
+    "d2s_colsum_f32": (I, [P, L, I, I, P, I, P, Z]),
+    "d2s_layernorm_fwd": (I, [P, L, L, L, L, P, P, P, P, P, L, I, F]),
+    "d2s_layernorm_bwd_workspace_bytes": (Z, [L, I]),
+    "d2s_layernorm_bwd": (I, [P, L, L, L, L, P, P, P, P, P, P, P, P, I, L, I, P, Z]),
+    "d2s_softmax_rows": (I, [P, P, I, I]),
+    "d2s_select_topk": (I, [P, I, I, I, P, P]),
+    "d2s_gather_pack_fwd": (I, [P, P, P, I, I, I, I]),
+    "d2s_scatter_unpack_bwd": (I, [P, P, P, I, I, I, I]),
+    "d2s_half_mean_concat": (I, [P, P, P, I, I, I]),
+    "d2s_im2col_patch": (I, [P, P, I, I, I, I, I]),
+    "d2s_fill_cls": (I, [P, P, P, I, I, I]),
+    "d2s_batch_sum": (I, [P, P, I, L, L, I]),
+    "d2s_copy_rows": (I, [P, L, L, L, L, P, L, I]),
+    "d2s_attn_fwd_f32": (I, [P, P, P, P, I, I, I, F]),
+    "d2s_attn_bwd_f32": (I, [P, P, P, P, P, P, I, I, I, F]),
+}
+
+_lib = None
+
+
+class D2SError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raises D2SError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise D2SError(f"{LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(or `make -C dense2sparse-vit_amd/csrc`). The d2s path has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = list(args) + ([P] if res is I else [])
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise D2SError("d2s ops need device tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point on the current stream; raise on error code."""
+    rc = getattr(load(), name)(*args, stream())
+    if rc != 0:
+        raise D2SError(f"{name} failed with code {rc}")
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)

@@ -1,0 +1,186 @@
+"""Tensor-level wrappers over the C ABI (one Python function per entry point, no arithmetic here).
+
+Conventions: fp32 contiguous device tensors unless a row map says otherwise; 2-D views [rows, features].
+"""
+import torch
+
+from . import lib
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_GELU, EPI_BIAS_RESID = 0, 1, 2, 3, 4
+EPI_MUL_GELU_GRAD, EPI_MUL_RELU_MASK, EPI_BIAS_ROWADD, EPI_ACCUM = 5, 6, 7, 8
+NT, NN, TN = 0, 1, 2
+
+_ws = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per device.  All d2s kernels run on one stream, so reuse is ordered."""
+    key = (device.type, device.index)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
+    return t
+
+
+def gemm(layout, A, lda, B, ldb, C, ldc, M, N, K, epi=EPI_NONE, bias=None, aux=None, ldaux=0, aux_out=None, aux_rows=0,
+         remap_rows=0, remap_skip=0, accumulate=False):
+    need = lib.query("d2s_gemm_f32_workspace_bytes", layout, M, N, K)
+    ws = workspace(need, C.device) if need else None
+    lib.call("d2s_gemm_f32", layout, lib.ptr(A), lda, lib.ptr(B), ldb, lib.ptr(C), ldc, M, N, K, epi, lib.ptr(bias),
+             lib.ptr(aux), ldaux, lib.ptr(aux_out), aux_rows, remap_rows, remap_skip, int(accumulate), lib.ptr(ws),
+             ws.numel() if ws is not None else 0)
+    return C
+
+
+def linear_fwd(x, W, bias=None, epi=None, aux=None, aux_out=None, out=None):
+    """y[M,N] = epi(x[M,K] @ W[N,K]^T + bias).  nn.Linear forward (F.linear)."""
+    _f32(x), _f32(W)
+    M, K = x.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if epi is None:
+        epi = EPI_BIAS if bias is not None else EPI_NONE
+    return gemm(NT, x, K, W, K, out, N, M, N, K, epi, bias, aux, N if aux is not None else 0, aux_out)
+
+
+def linear_dgrad(dy, W, epi=EPI_NONE, aux=None, out=None):
+    """dx[M,K] = epi(dy[M,N] @ W[N,K])."""
+    _f32(dy), _f32(W)
+    M, N = dy.shape
+    K = W.shape[1]
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    return gemm(NN, dy, N, W, K, out, K, M, K, N, epi, None, aux, K if aux is not None else 0)
+
+
+def linear_wgrad(dy, x, dW, accumulate=False):
+    """dW[N,K] (+)= dy[M,N]^T @ x[M,K]."""
+    _f32(dy), _f32(x), _f32(dW)
+    M, N = dy.shape
+    K = x.shape[1]
+    return gemm(TN, dy, N, x, K, dW, K, N, K, M, accumulate=accumulate)
+
+
+def colsum(x, out, accumulate=False):
+    _f32(x)
+    M, N = x.shape
+    need = lib.query("d2s_colsum_workspace_bytes", M, N)
+    ws = workspace(need, x.device)
+    lib.call("d2s_colsum_f32", lib.ptr(x), N, M, N, lib.ptr(out), int(accumulate), lib.ptr(ws), ws.numel())
+    return out
+
+
+def contiguous_map(rows, D):
+    return (rows, 0, D, 0)
+
+
+def skip_cls_map(n, D):
+    """rows of x[:, 1:] inside a contiguous [B, n, D] buffer."""
+    return (n - 1, n * D, D, D)
+
+
+def layernorm_fwd(x, rowmap, w, b, rows, D, eps):
+    y = torch.empty((rows, D), dtype=torch.float32, device=x.device)
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    lib.call("d2s_layernorm_fwd", lib.ptr(x), *rowmap, lib.ptr(w), lib.ptr(b), lib.ptr(y), lib.ptr(mean), lib.ptr(rstd),
+             rows, D, float(eps))
+    return y, mean, rstd
+
+
+def layernorm_bwd(x, rowmap, dy, w, mean, rstd, dx, add_src, dw, db, rows, D, accumulate_wb=False):
+    need = lib.query("d2s_layernorm_bwd_workspace_bytes", rows, D)
+    ws = workspace(need, dy.device)
+    lib.call("d2s_layernorm_bwd", lib.ptr(x), *rowmap, lib.ptr(dy), lib.ptr(w), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dx),
+             lib.ptr(add_src), lib.ptr(dw), lib.ptr(db), int(accumulate_wb), rows, D, lib.ptr(ws), ws.numel())
+    return dx
+
+
+def softmax_rows(scores):
+    _f32(scores)
+    R, T = scores.shape
+    probs = torch.empty_like(scores)
+    lib.call("d2s_softmax_rows", lib.ptr(scores), lib.ptr(probs), R, T)
+    return probs
+
+
+def select_topk(probs, k):
+    _f32(probs)
+    B, T = probs.shape
+    k = min(int(k), T)
+    kept = torch.empty((B, k), dtype=torch.int64, device=probs.device)
+    dropped = torch.empty((B, T - k), dtype=torch.int64, device=probs.device)
+    lib.call("d2s_select_topk", lib.ptr(probs), B, T, k, lib.ptr(kept), lib.ptr(dropped) if T - k > 0 else None)
+    return kept, dropped
+
+
+def gather_pack(x, ids):
+    _f32(x)
+    B, n, D = x.shape
+    k = ids.shape[1]
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    out = torch.empty((B, k + 1, D), dtype=torch.float32, device=x.device)
+    lib.call("d2s_gather_pack_fwd", lib.ptr(x), lib.ptr(ids), lib.ptr(out), B, n, k, D)
+    return out
+
+
+def scatter_unpack(g, ids, n):
+    _f32(g)
+    B, k1, D = g.shape
+    dx = torch.empty((B, n, D), dtype=torch.float32, device=g.device)
+    lib.call("d2s_scatter_unpack_bwd", lib.ptr(g), lib.ptr(ids), lib.ptr(dx), B, n, k1 - 1, D)
+    return dx
+
+
+def half_mean_concat(x, B, T, C, relu_mask_src=None):
+    out = torch.empty((B * T, C), dtype=torch.float32, device=x.device)
+    lib.call("d2s_half_mean_concat", lib.ptr(x), lib.ptr(relu_mask_src), lib.ptr(out), B, T, C)
+    return out
+
+
+def im2col_patch(img, P):
+    _f32(img)
+    B, Cin, H, W = img.shape
+    T = (H // P) * (W // P)
+    col = torch.empty((B * T, Cin * P * P), dtype=torch.float32, device=img.device)
+    lib.call("d2s_im2col_patch", lib.ptr(img), lib.ptr(col), B, Cin, H, W, P)
+    return col
+
+
+def fill_cls(cls, pos, tokens):
+    B, n, D = tokens.shape
+    lib.call("d2s_fill_cls", lib.ptr(cls), lib.ptr(pos), lib.ptr(tokens), B, n, D)
+
+
+def batch_sum(g, out, B, count, image_stride, accumulate=False):
+    lib.call("d2s_batch_sum", lib.ptr(g), lib.ptr(out), B, count, image_stride, int(accumulate))
+    return out
+
+
+def copy_rows(src, rowmap, rows, D):
+    dst = torch.empty((rows, D), dtype=torch.float32, device=src.device)
+    lib.call("d2s_copy_rows", lib.ptr(src), *rowmap, lib.ptr(dst), rows, D)
+    return dst
+
+
+def attn_fwd(qkv, B, n, H, scale, want_cls=True):
+    out = torch.empty((B * n, H * 64), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device)
+    cls_row = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device) if want_cls else None
+    lib.call("d2s_attn_fwd_f32", lib.ptr(qkv), lib.ptr(out), lib.ptr(lse), lib.ptr(cls_row), B, n, H, float(scale))
+    return out, lse, cls_row
+
+
+def attn_bwd(qkv, out, dout, lse, B, n, H, scale):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device)
+    lib.call("d2s_attn_bwd_f32", lib.ptr(qkv), lib.ptr(out), lib.ptr(dout), lib.ptr(lse), lib.ptr(dqkv), lib.ptr(delta), B, n, H,
+             float(scale))
+    return dqkv

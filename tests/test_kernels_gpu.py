@@ -1,0 +1,231 @@
+"""GPU tier, per-kernel parity: every HIP entry point (called through the C ABI) against the CPU oracle / plain torch
+fp32 CPU ops on the same seeded inputs.  Integer outputs must be bit-exact; floating point within the tolerance
+written at each assert."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import cases
+from oracle import d2s_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _rand(name, shape, std=1.0, seed=1):
+    from d2s import synth
+    return torch.from_numpy(synth.normal(name, shape, std=std, seed=seed))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from d2s import ops as _ops
+    return _ops
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(197 * 2, 1152, 384), (99 * 3, 384, 1536), (128, 1000, 384), (300, 96, 192),
+                                   (50, 1, 96), (4, 10, 128), (391, 200, 36), (1024, 1536, 384)])
+def test_gemm_nt_bias(ops, M, N, K):
+    x, w, b = _rand("gx", (M, K)), _rand("gw", (N, K), 0.05), _rand("gb", (N,), 0.1)
+    ref = F.linear(x, w, b)
+    got = ops.linear_fwd(x.to(_dev()), w.to(_dev()), b.to(_dev())).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_gemm_epilogues(ops):
+    M, N, K = 333, 520, 136
+    x, w, b, r = _rand("ex", (M, K)), _rand("ew", (N, K), 0.1), _rand("eb", (N,), 0.1), _rand("er", (M, N))
+    xd, wd, bd, rd = (t.to(_dev()) for t in (x, w, b, r))
+    z = F.linear(x, w, b)
+    np.testing.assert_allclose(ops.linear_fwd(xd, wd, bd, epi=ops.EPI_BIAS_RELU).cpu().numpy(), F.relu(z).numpy(), rtol=1e-4, atol=2e-5)
+    pre = torch.empty((M, N), device=_dev())
+    g = ops.linear_fwd(xd, wd, bd, epi=ops.EPI_BIAS_GELU, aux_out=pre).cpu()
+    np.testing.assert_allclose(g.numpy(), F.gelu(z).numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(pre.cpu().numpy(), z.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(ops.linear_fwd(xd, wd, bd, epi=ops.EPI_BIAS_RESID, aux=rd).cpu().numpy(), (z + r).numpy(), rtol=1e-4, atol=2e-5)
+    # dgrad with activation-gradient epilogues
+    dy = _rand("edy", (M, N))
+    w2 = _rand("ew2", (N, K), 0.1)       # dx[M,K] = dy @ w2
+    pre_k = _rand("epk", (M, K))
+    dx = dy @ w2
+    zz = pre_k.clone().requires_grad_(True)
+    F.gelu(zz).backward(torch.ones_like(zz))
+    got = ops.linear_dgrad(dy.to(_dev()), w2.to(_dev()), epi=ops.EPI_MUL_GELU_GRAD, aux=pre_k.to(_dev())).cpu()
+    np.testing.assert_allclose(got.numpy(), (dx * zz.grad).numpy(), rtol=1e-4, atol=3e-5)
+    got = ops.linear_dgrad(dy.to(_dev()), w2.to(_dev()), epi=ops.EPI_MUL_RELU_MASK, aux=pre_k.to(_dev())).cpu()
+    np.testing.assert_allclose(got.numpy(), (dx * (pre_k > 0)).numpy(), rtol=1e-4, atol=3e-5)
+    got = ops.linear_dgrad(dy.to(_dev()), w2.to(_dev())).cpu()
+    np.testing.assert_allclose(got.numpy(), dx.numpy(), rtol=1e-4, atol=3e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(197 * 8, 1536, 384), (99 * 5, 384, 1536), (700, 10, 128), (5000, 1, 96), (64, 96, 192)])
+def test_gemm_wgrad_and_colsum(ops, M, N, K):
+    dy, x = _rand("wdy", (M, N), 0.5), _rand("wx", (M, K))
+    ref = dy.t().double() @ x.double()
+    dW = torch.zeros((N, K), device=_dev())
+    ops.linear_wgrad(dy.to(_dev()), x.to(_dev()), dW)
+    np.testing.assert_allclose(dW.cpu().numpy(), ref.float().numpy(), rtol=2e-4, atol=2e-4)
+    base = _rand("wbase", (N, K))
+    dW2 = base.to(_dev()).clone()
+    ops.linear_wgrad(dy.to(_dev()), x.to(_dev()), dW2, accumulate=True)
+    np.testing.assert_allclose(dW2.cpu().numpy(), (ref.float() + base).numpy(), rtol=2e-4, atol=2e-4)
+    db = torch.zeros((N,), device=_dev())
+    ops.colsum(dy.to(_dev()), db)
+    np.testing.assert_allclose(db.cpu().numpy(), dy.double().sum(0).float().numpy(), rtol=1e-4, atol=1e-4)
+    ops.colsum(dy.to(_dev()), db, accumulate=True)
+    np.testing.assert_allclose(db.cpu().numpy(), 2 * dy.double().sum(0).float().numpy(), rtol=1e-4, atol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,D,eps", [(197 * 2, 384, 1e-6), (99 * 3, 1536, 1e-5), (77, 96, 1e-5), (50, 192, 1e-6),
+                                        (33, 48, 1e-5), (20, 3072, 1e-5), (10, 128, 1e-6), (9, 768, 1e-6)])
+def test_layernorm_fwd_bwd(ops, rows, D, eps):
+    x = _rand("lx", (rows, D), 2.0) + 0.3
+    w, b = 1 + _rand("lw", (D,), 0.2), _rand("lb", (D,), 0.2)
+    dy, add = _rand("ldy", (rows, D)), _rand("ladd", (rows, D))
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (D,), wr, br, eps)
+    ref.backward(dy)
+    xd, wd, bd = x.to(_dev()), w.to(_dev()), b.to(_dev())
+    y, mean, rstd = ops.layernorm_fwd(xd, ops.contiguous_map(rows, D), wd, bd, rows, D, eps)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    dx = torch.empty((rows, D), device=_dev())
+    dw, db = torch.zeros((D,), device=_dev()), torch.zeros((D,), device=_dev())
+    ops.layernorm_bwd(xd, ops.contiguous_map(rows, D), dy.to(_dev()), wd, mean, rstd, dx, add.to(_dev()), dw, db, rows, D)
+    np.testing.assert_allclose(dx.cpu().numpy(), (xr.grad + add).numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(dw.cpu().numpy(), wr.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_layernorm_skip_cls_rowmap(ops):
+    B, n, D = 3, 17, 128
+    x = _rand("sx", (B, n, D))
+    w, b = 1 + _rand("sw", (D,), 0.2), _rand("sb", (D,), 0.2)
+    rows = B * (n - 1)
+    ref = F.layer_norm(x[:, 1:], (D,), w, b, 1e-5).reshape(rows, D)
+    xd = x.to(_dev())
+    y, mean, rstd = ops.layernorm_fwd(xd, ops.skip_cls_map(n, D), w.to(_dev()), b.to(_dev()), rows, D, 1e-5)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+    # backward adds into rows 1.. of a [B,n,D] gradient buffer, CLS rows untouched
+    dy = _rand("sdy", (rows, D))
+    gbuf = _rand("sg", (B, n, D))
+    xr = x.clone().requires_grad_(True)
+    F.layer_norm(xr[:, 1:], (D,), w, b, 1e-5).backward(dy.reshape(B, n - 1, D))
+    gd = gbuf.to(_dev())
+    ops.layernorm_bwd(xd, ops.skip_cls_map(n, D), dy.to(_dev()), w.to(_dev()), mean, rstd, gd, gd, None, None, rows, D)
+    np.testing.assert_allclose(gd.cpu().numpy(), (gbuf + xr.grad).numpy(), rtol=1e-4, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ selection path
+def test_softmax_rows(ops):
+    s = _rand("sm", (37, 196), 1.5)
+    got = ops.softmax_rows(s.to(_dev())).cpu()
+    np.testing.assert_allclose(got.numpy(), F.softmax(s, dim=-1).numpy(), rtol=2e-6, atol=1e-9)
+    s = _rand("sm2", (5, 577), 3.0)
+    np.testing.assert_allclose(ops.softmax_rows(s.to(_dev())).cpu().numpy(), F.softmax(s, dim=-1).numpy(), rtol=2e-6, atol=1e-9)
+
+
+def test_select_topk_bit_exact_on_reference_fixture(ops):
+    g = cases.load_golden("selection")
+    checked = 0
+    for key in g.files:
+        if not key.startswith("kept_"):
+            continue
+        _, N, k = key.split("_")
+        N, k = int(N), int(k)
+        probs = torch.from_numpy(g[f"probs_{N}"])
+        kept, dropped = ops.select_topk(probs.to(_dev()), k)
+        kept, dropped = kept.cpu(), dropped.cpu()
+        assert kept.dtype == torch.int64
+        rows = [r for r in range(probs.shape[0]) if r not in (8, 9)]
+        np.testing.assert_array_equal(kept.numpy()[rows], g[key][rows])              # the reference's own output
+        np.testing.assert_array_equal(dropped.numpy()[rows], g[f"dropped_{N}_{k}"][rows])
+        ks, ds = O.select_topk_stable(probs, k)                                      # incl. the mass-tie rows
+        np.testing.assert_array_equal(kept.numpy(), ks.numpy())
+        np.testing.assert_array_equal(dropped.numpy(), ds.numpy())
+        checked += 1
+    assert checked >= 9
+
+
+@pytest.mark.parametrize("B,n,k,D", [(4, 197, 98, 384), (3, 197, 137, 384), (2, 138, 98, 384), (5, 17, 9, 128),
+                                     (2, 5, 4, 192), (2, 577, 172, 768), (3, 99, 0, 64), (2, 10, 9, 32)])
+def test_gather_scatter_roundtrip(ops, B, n, k, D):
+    x = _rand("gsx", (B, n, D))
+    probs = torch.rand((B, n - 1), generator=torch.Generator().manual_seed(3))
+    kept, _ = O.select_topk_stable(probs, k)
+    ref = O.gather_pack(x, kept)
+    got = ops.gather_pack(x.to(_dev()), kept.to(_dev()))
+    np.testing.assert_array_equal(got.cpu().numpy(), ref.numpy())                    # byte moves: exact
+    g = _rand("gsg", (B, k + 1, D))
+    xr = x.clone().requires_grad_(True)
+    O.gather_pack(xr, kept).backward(g)
+    dx = ops.scatter_unpack(g.to(_dev()), kept.to(_dev()), n)
+    np.testing.assert_array_equal(dx.cpu().numpy(), xr.grad.numpy())
+    # encode -> decode round trip: gather(scatter(g)) == g
+    np.testing.assert_array_equal(ops.gather_pack(dx, kept.to(_dev())).cpu().numpy(), g.numpy())
+
+
+def test_half_mean_concat(ops):
+    B, T, C = 3, 37, 512
+    x = _rand("hx", (B, T, C))
+    ref = torch.cat([x[:, :, :C // 2], x[:, :, C // 2:].mean(dim=1, keepdim=True).expand(B, T, C // 2)], dim=-1)
+    got = ops.half_mean_concat(x.to(_dev()), B, T, C).cpu().reshape(B, T, C)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    mask = _rand("hm", (B, T, C))
+    got = ops.half_mean_concat(x.to(_dev()), B, T, C, relu_mask_src=mask.to(_dev())).cpu().reshape(B, T, C)
+    np.testing.assert_allclose(got.numpy(), (ref * (mask > 0)).numpy(), rtol=1e-5, atol=1e-6)
+    # odd half width (small predictor of DeiT-Tiny: C = 192)
+    B, T, C = 2, 9, 192
+    x = _rand("hx2", (B, T, C))
+    ref = torch.cat([x[:, :, :C // 2], x[:, :, C // 2:].mean(dim=1, keepdim=True).expand(B, T, C // 2)], dim=-1)
+    np.testing.assert_allclose(ops.half_mean_concat(x.to(_dev()), B, T, C).cpu().reshape(B, T, C).numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_patch_embed_matches_oracle(ops):
+    case = cases.MODEL_CASES["micro1"]
+    cfg = case["cfg"]
+    sd = {k: torch.from_numpy(v) for k, v in cases.make_weights(case)[0].items()}
+    x = torch.from_numpy(cases.make_images(case))
+    ref = O.embed_tokens(sd, x, cfg)
+    B, T, D, P = x.shape[0], cfg["n_patches"], cfg["dim"], cfg["patch"]
+    col = ops.im2col_patch(x.to(_dev()), P)
+    tokens = torch.empty((B, T + 1, D), device=_dev())
+    w = sd["patch_embed.proj.weight"].reshape(D, -1).contiguous().to(_dev())
+    pos = sd["pos_embed"].reshape(T + 1, D).contiguous().to(_dev())
+    ops.gemm(ops.NT, col, col.shape[1], w, w.shape[1], tokens, D, B * T, D, col.shape[1], ops.EPI_BIAS_ROWADD,
+             sd["patch_embed.proj.bias"].to(_dev()), pos[1:], D, None, T, T, 1)
+    ops.fill_cls(sd["cls_token"].reshape(D).to(_dev()), pos, tokens)
+    np.testing.assert_allclose(tokens.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+    g = cases.load_golden("intermediates_micro1")
+    np.testing.assert_allclose(tokens.cpu().numpy(), g["tokens0"], rtol=1e-4, atol=2e-5)   # the reference's own output
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(qkv, B, n, H):
+    q, k, v = qkv.reshape(B, n, 3, H, 64).permute(2, 0, 3, 1, 4)
+    a = ((q @ k.transpose(-2, -1)) * 0.125).softmax(dim=-1)
+    o = (a @ v).transpose(1, 2).reshape(B, n, H * 64)
+    return o, a[:, :, 0, :], torch.logsumexp((q @ k.transpose(-2, -1)) * 0.125, dim=-1)
+
+
+@pytest.mark.parametrize("B,n,H", [(2, 197, 6), (3, 99, 3), (2, 59, 2), (2, 17, 2), (1, 5, 3), (2, 138, 6), (1, 577, 2),
+                                   (2, 32, 1), (1, 129, 1), (1, 1, 1)])
+def test_attention_fwd_bwd(ops, B, n, H):
+    qkv = _rand("aq", (B * n, 3 * H * 64), 1.0, seed=n)
+    qr = qkv.clone().requires_grad_(True)
+    o_ref, cls_ref, lse_ref = _attn_ref(qr, B, n, H)
+    do = _rand("ado", (B, n, H * 64), 1.0, seed=n + 1)
+    o_ref.backward(do)
+    qd = qkv.to(_dev())
+    out, lse, cls_row = ops.attn_fwd(qd, B, n, H, 0.125)
+    np.testing.assert_allclose(out.cpu().numpy().reshape(B, n, -1), o_ref.detach().numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(cls_row.cpu().numpy(), cls_ref.detach().numpy(), rtol=1e-4, atol=1e-7)
+    dqkv = ops.attn_bwd(qd, out, do.reshape(B * n, -1).to(_dev()), lse, B, n, H, 0.125)
+    np.testing.assert_allclose(dqkv.cpu().numpy(), qr.grad.numpy(), rtol=2e-4, atol=5e-5)
