@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ w, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, float* __restrict__ dx, RowMap dxm,
                                                      const float* __restrict__ add_src, float* __restrict__ part,
-                                                     long rows, int D, long rows_per_block) {
+                                                     long rows, int D, long rows_per_block, int relu_mask) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [3][2][D]  (waves 1..3)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = D >> 2;
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         const float* gr = dy + row * D;
         const float mean = mean_in[row], rstd = rstd_in[row];
         f32x4 xh[NV], g[NV];
+        unsigned pos[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -107,8 +108,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
             if (c < nvec) {
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c * 4);
                 g[i] = *reinterpret_cast<const f32x4*>(gr + c * 4);
+                pos[i] = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    pos[i] |= (xv[j] > 0.f ? 1u : 0u) << j;
                     xh[i][j] = (xv[j] - mean) * rstd;
                     const float gw = g[i][j] * wv[i][j];
                     s1 += gw;
@@ -128,6 +131,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] * wv[i][j] - s1 - xh[i][j] * s2);
+                if (relu_mask) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = ((pos[i] >> j) & 1u) ? o[j] : 0.f;
+                }
                 if (add_src) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(add_src + doff + c * 4);
 #pragma unroll
@@ -220,12 +227,14 @@ int d2s_layernorm_fwd(const float* x, long rows_per_group, long group_stride, lo
 
 size_t d2s_layernorm_bwd_workspace_bytes(long rows, int D) { return (size_t)bwd_blocks(rows) * 2 * D * sizeof(float); }
 
-// dx[map(r)] = (add_src ? add_src[map(r)] : 0) + dLN/dx ; dweight / dbias (+)= column sums (skipped if dweight null).
+// dx[map(r)] = (add_src ? add_src[map(r)] : 0) + mask * dLN/dx ; dweight / dbias (+)= column sums (skipped if dweight
+// null).  relu_mask != 0: mask = (x > 0), i.e. the backward of a ReLU whose OUTPUT is this LayerNorm's input
+// (the predictor's Linear->ReLU->LayerNorm chain, dynamic_vit.py:515-528), folded into the same pass.
 // x and dx/add_src share one RowMap; dy, mean, rstd are contiguous per logical row.
 int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* dy,
                       const float* w, const float* mean, const float* rstd, float* dx, const float* add_src, float* dweight,
-                      float* dbias, int accumulate_wb, long rows, int D, void* workspace, size_t workspace_bytes,
-                      hipStream_t stream) {
+                      float* dbias, int accumulate_wb, int relu_mask, long rows, int D, void* workspace,
+                      size_t workspace_bytes, hipStream_t stream) {
     if (!x || !dy || !w || !mean || !rstd || !dx || rows <= 0 || D <= 0 || (D & 3) || D > 4096) return D2S_ERR_ARG;
     if ((group_stride | row_stride | offset) & 3) return D2S_ERR_ARG;
     const int nb = bwd_blocks(rows);
@@ -240,7 +249,7 @@ int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, lo
     const int nblocks = (int)((rows + rpb - 1) / rpb);
     dim3 grid(nblocks), block(256);
     const size_t sh = (size_t)3 * 2 * D * sizeof(float);
-#define D2S_LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, sh, stream, x, m, dy, w, mean, rstd, dx, m, add_src, part, rows, D, rpb)
+#define D2S_LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, sh, stream, x, m, dy, w, mean, rstd, dx, m, add_src, part, rows, D, rpb, relu_mask)
     switch (pick_nv(D)) {
         case 1: D2S_LN_BWD(1); break;
         case 2: D2S_LN_BWD(2); break;

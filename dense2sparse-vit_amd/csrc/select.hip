@@ -242,8 +242,9 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict_
 
 // generic row copy through a row map (strip the CLS rows of a gradient buffer, etc.)
 __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, long rows_per_group, long group_stride,
-                                                        long row_stride, long offset, float* __restrict__ dst, long rows,
-                                                        int D) {
+                                                        long row_stride, long offset, float* __restrict__ dst,
+                                                        long d_rows_per_group, long d_group_stride, long d_row_stride,
+                                                        long d_offset, long rows, int D) {
     const int nvec = D >> 2;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= rows * nvec) return;
@@ -251,7 +252,9 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
     const int c = (int)(e - r * nvec);
     const long g = r / rows_per_group, t = r - g * rows_per_group;
     const float* s = src + g * group_stride + offset + t * row_stride;
-    reinterpret_cast<f32x4*>(dst)[e] = reinterpret_cast<const f32x4*>(s)[c];
+    const long dg = r / d_rows_per_group, dt = r - dg * d_rows_per_group;
+    float* d = dst + dg * d_group_stride + d_offset + dt * d_row_stride;
+    reinterpret_cast<f32x4*>(d)[c] = reinterpret_cast<const f32x4*>(s)[c];
 }
 
 }  // namespace
@@ -266,7 +269,7 @@ int d2s_softmax_rows(const float* scores, float* probs, int rows, int T, hipStre
 
 // probs [B,T] fp32 -> kept [B,k] int64 ascending, dropped [B,T-k] int64 ascending (may be null).  k is clamped to T.
 int d2s_select_topk(const float* probs, int B, int T, int k, long long* kept, long long* dropped, hipStream_t stream) {
-    if (!probs || !kept || B <= 0 || T <= 0 || k < 0 || k > T || T > 16384) return D2S_ERR_ARG;
+    if (!probs || (!kept && k > 0) || B <= 0 || T <= 0 || k < 0 || k > T || T > 16384) return D2S_ERR_ARG;
     if (k == 0 && !dropped) return D2S_OK;
     hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(256), (size_t)2 * T * sizeof(float), stream, probs, T, k, kept,
                        (T - k) > 0 ? dropped : nullptr);
@@ -317,13 +320,15 @@ int d2s_batch_sum(const float* g, float* out, int B, long count, long image_stri
     return d2s_check_launch();
 }
 
-int d2s_copy_rows(const float* src, long rows_per_group, long group_stride, long row_stride, long offset, float* dst, long rows,
-                  int D, hipStream_t stream) {
-    if (!src || !dst || rows <= 0 || D <= 0 || (D & 3) || rows_per_group <= 0) return D2S_ERR_ARG;
-    if ((group_stride | row_stride | offset) & 3) return D2S_ERR_ARG;
+// row r of src (through the source row map) -> row r of dst (through the destination row map)
+int d2s_copy_rows(const float* src, long rows_per_group, long group_stride, long row_stride, long offset, float* dst,
+                  long d_rows_per_group, long d_group_stride, long d_row_stride, long d_offset, long rows, int D,
+                  hipStream_t stream) {
+    if (!src || !dst || rows <= 0 || D <= 0 || (D & 3) || rows_per_group <= 0 || d_rows_per_group <= 0) return D2S_ERR_ARG;
+    if ((group_stride | row_stride | offset | d_group_stride | d_row_stride | d_offset) & 3) return D2S_ERR_ARG;
     const long total = rows * (D >> 2);
     hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, rows_per_group,
-                       group_stride, row_stride, offset, dst, rows, D);
+                       group_stride, row_stride, offset, dst, d_rows_per_group, d_group_stride, d_row_stride, d_offset, rows, D);
     return d2s_check_launch();
 }
 

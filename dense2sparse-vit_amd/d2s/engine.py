@@ -1,0 +1,256 @@
+"""Training engine for the accelerated step: flat parameter / gradient arenas in HBM, fused AdamW, the step of
+train.py:40-57, and the data-parallel gradient exchange (ddp_training.py:93 intent) as bucketed RCCL all-reduces on a
+side stream that overlap the rest of backward.
+
+Layout: every student parameter lives in ONE fp32 arena (each tensor padded to 1024 elements); gradients, exp_avg and
+exp_avg_sq have arenas of the same layout.  The Functions in d2s.functional write parameter gradients straight into
+the gradient arena (ops.grad_buffer), so the optimiser is a single kernel launch and a DDP bucket is a contiguous
+slice - there is no flatten/unflatten copy anywhere.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import lib, ops
+
+
+def _group_of(name, p):
+    """utils.get_param_groups, utils.py:67-90 -> 'predictor' | 'base_no_decay' | 'base_decay' | None (never optimised)."""
+    if "predictor" in name or "dist" in name:
+        return "predictor"
+    if "early_exit" in name:
+        return "early_exit"
+    if "cls_token" in name or "pos_embed" in name:
+        return None
+    if p.dim() == 1 or name.endswith(".bias"):
+        return "base_no_decay"
+    return "base_decay"
+
+
+class ParamArena:
+    """Moves the parameters of `model` into one flat fp32 buffer (in registration order) and owns the matching
+    gradient buffer.  param.data becomes a view; state_dict()/load_state_dict() keep working."""
+
+    def __init__(self, model, order=None):
+        self.chunk = lib.query("d2s_adamw_chunk_elems")
+        named = [(n, p) for n, p in model.named_parameters()]
+        if order is not None:
+            byname = dict(named)
+            assert sorted(order) == sorted(byname), "order must list every parameter exactly once"
+            named = [(n, byname[n]) for n in order]
+        assert named and all(p.is_cuda and p.dtype == torch.float32 for _, p in named), "move the model to the GPU first"
+        dev = named[0][1].device
+        self.names, self.offsets, self.sizes, self.params_list = [], [], [], []
+        off = 0
+        for n, p in named:
+            self.names.append(n)
+            self.offsets.append(off)
+            self.sizes.append(p.numel())
+            self.params_list.append(p)
+            off += ((p.numel() + self.chunk - 1) // self.chunk) * self.chunk
+        self.total = off
+        self.n_chunks = off // self.chunk
+        self.params = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad_views = {}
+        for n, p, o, s in zip(self.names, self.params_list, self.offsets, self.sizes):
+            v = self.params[o:o + s].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            gv = self.grads[o:o + s].view(p.shape)
+            self.grad_views[n] = gv
+            ops.register_grad_buffer(p, gv)
+
+    def chunk_range(self, i):
+        o = self.offsets[i]
+        return o // self.chunk, (o + ((self.sizes[i] + self.chunk - 1) // self.chunk) * self.chunk) // self.chunk
+
+    def collect_grads(self):
+        """Make sure every live gradient sits in the arena (it does when the Functions produced it; a gradient that
+        autograd materialised elsewhere is copied in) and detach .grad from autograd's bookkeeping."""
+        for n, p in zip(self.names, self.params_list):
+            if p.grad is not None and p.grad.data_ptr() != self.grad_views[n].data_ptr():
+                self.grad_views[n].copy_(p.grad)
+
+
+class FusedAdamW:
+    """torch.optim.AdamW semantics (decoupled weight decay, bias correction) over a ParamArena in one kernel launch.
+    Groups and learning rates follow utils.get_param_groups / utils.adjust_learning_rate (utils.py:67-147)."""
+
+    def __init__(self, arena, lr=5e-4, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8):
+        self.arena, self.betas, self.eps = arena, betas, eps
+        self.exp_avg = torch.zeros_like(arena.params)
+        self.exp_avg_sq = torch.zeros_like(arena.params)
+        self.groups = [_group_of(n, p) for n, p in zip(arena.names, arena.params_list)]
+        self.group_lr = {"predictor": lr, "base_no_decay": lr, "base_decay": lr, "early_exit": lr}
+        self.group_wd = {"predictor": weight_decay, "base_no_decay": 0.0, "base_decay": weight_decay, "early_exit": weight_decay}
+        self.steps = 0
+        self._desc = None
+        self._dirty = True
+
+    def set_lrs(self, predictor_lr, backbone_lr):
+        self.group_lr.update(predictor=predictor_lr, base_no_decay=backbone_lr, base_decay=backbone_lr)
+        self._dirty = True
+
+    def _build_desc(self):
+        a = self.arena
+        desc = np.zeros(a.n_chunks, dtype=[("lr", "<f4"), ("wd", "<f4"), ("active", "<i4"), ("pad", "<i4")])
+        for i, (g, p) in enumerate(zip(self.groups, a.params_list)):
+            c0, c1 = a.chunk_range(i)
+            if g is None or not p.requires_grad:
+                continue
+            desc["lr"][c0:c1] = self.group_lr[g]
+            desc["wd"][c0:c1] = self.group_wd[g]
+            desc["active"][c0:c1] = 1
+        self._desc = torch.from_numpy(desc.view(np.uint8).copy()).to(a.params.device)
+        self._dirty = False
+
+    def mark_dirty(self):
+        self._dirty = True
+
+    def step(self, grad_scale=1.0):
+        if self._dirty:
+            self._build_desc()
+        self.steps += 1
+        a = self.arena
+        ops.adamw_step(a.params, a.grads, self.exp_avg, self.exp_avg_sq, self._desc, a.n_chunks, self.betas[0], self.betas[1],
+                       self.eps, self.steps, grad_scale)
+
+    def zero_grad(self):
+        for p in self.arena.params_list:
+            p.grad = None
+
+
+def adjust_learning_rate(optimizer, model, step, epochs, lr, min_lr, warmup_steps):
+    """utils.adjust_learning_rate (utils.py:93-147): cosine schedule, backbone frozen for the first `warmup_steps`
+    epochs (requires_grad toggled exactly like the reference), backbone lr = min(0.01 lr, cos) afterwards."""
+    cos_lr = (math.cos(step / epochs * math.pi) + 1) * 0.5
+    cos_lr = min_lr + cos_lr * (lr - min_lr)
+    predictor_lr = cos_lr
+    backbone_lr = 0.0 if step < warmup_steps else min(lr * 0.01, cos_lr)
+    for n, p in model.named_parameters():
+        is_pred = "dist" in n or "predictor" in n
+        g = _group_of(n, p)
+        if g is None:                       # cls_token / pos_embed: in no param group, follow the first loop of the reference
+            p.requires_grad_(True if step >= warmup_steps else is_pred)
+        elif g == "predictor":
+            p.requires_grad_(predictor_lr != 0)
+        else:
+            p.requires_grad_(backbone_lr != 0)
+    optimizer.set_lrs(predictor_lr, backbone_lr)
+    return predictor_lr, backbone_lr
+
+
+def execution_order(student):
+    """Parameter names in forward-execution order (embed, then per block: the predictor that runs before it, the block;
+    then norm / head).  Autograd runs backward in exactly the reverse order, so gradients become final from the END of
+    an arena laid out this way towards its start - which is what makes a DDP bucket a contiguous tail slice."""
+    names = [n for n, _ in student.named_parameters()]
+    pre = [n for n in names if not (n.startswith("blocks.") or n.startswith("score_predictor.") or n.startswith("norm.")
+                                    or n.startswith("head."))]
+    order, starts = list(pre), {}
+    locs = list(getattr(student, "pruning_loc", []))
+    for i in range(len(student.blocks)):
+        starts[i] = len(order)
+        if i in locs:
+            s_ = locs.index(i)
+            order += [n for n in names if n.startswith(f"score_predictor.{s_}.")]
+        order += [n for n in names if n.startswith(f"blocks.{i}.")]
+    order += [n for n in names if n.startswith("norm.") or n.startswith("head.")]
+    assert sorted(order) == sorted(names)
+    return order, starts
+
+
+class GradReducer:
+    """Data-parallel gradient averaging (the DDP of ddp_training.py:93): tail slices of the gradient arena are
+    all-reduced with RCCL on a side stream as soon as autograd has finished the layers that own them (reverse layer
+    order), so the exchange overlaps the remaining backward; joined before the optimiser step."""
+
+    def __init__(self, arena, group=None, bucket_mb=16.0):
+        self.arena, self.group = arena, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.stream = torch.cuda.Stream() if arena.params.is_cuda else None
+        self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
+        self._hi = arena.total
+        self._works = []
+
+    def _launch(self, lo):
+        hi, self._hi = self._hi, lo
+        if self.world == 1 or lo >= hi:
+            return
+        buf = self.arena.grads[lo:hi]
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def ready_from(self, lo):
+        """Every gradient at arena offset >= lo is final."""
+        if self._hi - lo >= self.bucket_elems:
+            self._launch(lo)
+
+    def finish(self):
+        """Flush the remainder, join, and return 1/world (folded into the optimiser's gradient scale)."""
+        self._launch(0)
+        for w in self._works:
+            w.wait()
+        if self.world > 1 and self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self._works = []
+        self._hi = self.arena.total
+        return 1.0 / self.world
+
+
+class TrainStep:
+    """One optimiser step as train.py:40-57 defines it: teacher forward (no grad), student forward, MaskLoss +
+    BackboneLoss, warm-up switch (train.py:50-53), zero_grad / backward / step."""
+
+    def __init__(self, student, teacher, args, lr=5e-4, min_lr=1e-5, weight_decay=0.05, epochs=25, warmup_steps=0,
+                 distributed=False, bucket_mb=16.0):
+        from losses import MaskLoss, BackboneLoss
+        self.student, self.teacher, self.args = student, teacher, args
+        self.teacher.eval()
+        for p in self.teacher.parameters():
+            p.requires_grad_(False)
+        order, starts = execution_order(student)
+        self.arena = ParamArena(student, order)
+        self.block_offset = {i: self.arena.offsets[starts[i]] for i in starts}
+        self.opt = FusedAdamW(self.arena, lr=lr, weight_decay=weight_decay)
+        self.mask_loss_fn = MaskLoss(args, "train")
+        self.backbone_loss_fn = BackboneLoss(args)
+        self.metrics = {}
+        self.lr, self.min_lr, self.epochs, self.warmup_steps = lr, min_lr, epochs, warmup_steps
+        self.reducer = GradReducer(self.arena, bucket_mb=bucket_mb) if distributed else None
+        if self.reducer is not None:
+            student.grad_ready_hook = lambda i: self.reducer.ready_from(self.block_offset[i])
+        self.set_epoch(0)
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+        self.args.step = epoch
+        return adjust_learning_rate(self.opt, self.student, epoch, self.epochs, self.lr, self.min_lr, self.warmup_steps)
+
+    def forward_losses(self, images, labels):
+        with torch.no_grad():
+            logits_t, token_t, cls_attn = self.teacher(images)
+        logits_s, token_s, pred_logits, kept = self.student(images)
+        mask_loss = self.mask_loss_fn(pred_logits, cls_attn, kept, self.metrics)
+        backbone_loss = self.backbone_loss_fn(logits_s, token_s, logits_t, token_t, kept, labels, self.metrics)
+        loss = mask_loss if self.epoch < self.warmup_steps else backbone_loss + mask_loss     # train.py:50-53
+        return loss, dict(mask_loss=mask_loss, backbone_loss=backbone_loss, kept=kept, logits_s=logits_s, token_s=token_s,
+                          pred_logits=pred_logits, logits_t=logits_t, token_t=token_t, cls_attn=cls_attn)
+
+    def __call__(self, images, labels):
+        self.student.train()
+        loss, info = self.forward_losses(images, labels)
+        self.opt.zero_grad()
+        loss.backward()
+        self.arena.collect_grads()
+        scale = self.reducer.finish() if self.reducer is not None else 1.0
+        self.opt.step(grad_scale=scale)
+        info["loss"] = loss.detach()
+        return info

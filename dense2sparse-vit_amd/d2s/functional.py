@@ -1,0 +1,410 @@
+"""Autograd glue: one torch.autograd.Function per module of the hot path.  Forward and backward are explicit
+sequences of C-ABI calls (d2s.ops); torch only owns the tensors and the graph.  No torch arithmetic runs here.
+
+Reference lines (relative to /root/reference):
+  EmbedFn      vit_models/dynamic_vit.py:300-306, 820-823
+  BlockFn      vit_models/dynamic_vit.py:263-269 (Block), :216-236 (Attention), :169-175 (Mlp)
+  PredictorFn  vit_models/dynamic_vit.py:536-551 with layers :491-531
+  GatherFn     vit_models/dynamic_vit.py:907-912
+  HeadFn       vit_models/dynamic_vit.py:993-1006
+"""
+import torch
+
+from . import ops
+
+_DH = 64
+
+
+def _zeros_like_param(p):
+    return torch.zeros_like(p)
+
+
+def _need(ctx, i):
+    return ctx.needs_input_grad[i]
+
+
+class EmbedFn(torch.autograd.Function):
+    """img [B,3,H,W] -> tokens [B, T+1, D]  (conv-as-GEMM with the bias + pos_embed add fused in the epilogue)."""
+
+    @staticmethod
+    def forward(ctx, img, proj_w, proj_b, cls_token, pos_embed, patch):
+        B = img.shape[0]
+        D = proj_w.shape[0]
+        col = ops.im2col_patch(img.contiguous(), patch)
+        T = col.shape[0] // B
+        Kc = col.shape[1]
+        tokens = torch.empty((B, T + 1, D), dtype=torch.float32, device=img.device)
+        w2 = proj_w.reshape(D, Kc)
+        pos = pos_embed.reshape(T + 1, D)
+        ops.gemm(ops.NT, col, Kc, w2, Kc, tokens, D, B * T, D, Kc, ops.EPI_BIAS_ROWADD, proj_b, pos[1:], D, None, T, T, 1)
+        ops.fill_cls(cls_token.reshape(D), pos, tokens)
+        ctx.save_for_backward(col, proj_w, proj_b, cls_token, pos_embed)
+        ctx.dims = (B, T, D, Kc, tuple(proj_w.shape))
+        return tokens
+
+    @staticmethod
+    def backward(ctx, g):
+        col, proj_w, proj_b, cls_token, pos_embed = ctx.saved_tensors
+        B, T, D, Kc, wshape = ctx.dims
+        g = g.contiguous()
+        dw = db = dcls = dpos = None
+        if _need(ctx, 1) or _need(ctx, 2):
+            gp = ops.copy_rows(g, ops.skip_cls_map(T + 1, D), B * T, D)
+            if _need(ctx, 1):
+                dw = ops.grad_buffer(proj_w)
+                ops.linear_wgrad(gp, col, dw.view(D, Kc))
+            if _need(ctx, 2):
+                db = ops.colsum(gp, ops.grad_buffer(proj_b))
+        if _need(ctx, 3) or _need(ctx, 4):
+            dpos = ops.grad_buffer(pos_embed)
+            ops.batch_sum(g, dpos, B, (T + 1) * D, (T + 1) * D)
+            if _need(ctx, 3):
+                dcls = ops.batch_sum(g, ops.grad_buffer(cls_token), B, D, (T + 1) * D)
+            if not _need(ctx, 4):
+                dpos = None
+        return None, dw, db, dcls, dpos, None
+
+
+class BlockFn(torch.autograd.Function):
+    """One pre-norm transformer block on a packed [B, n, D] token tensor; also returns the CLS row of the softmax."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, heads, eps, want_cls):
+        B, n, D = x.shape
+        M = B * n
+        x = x.contiguous()
+        scale = float(_DH) ** -0.5
+        cmap = ops.contiguous_map(M, D)
+        ln1, mean1, rstd1 = ops.layernorm_fwd(x, cmap, n1w, n1b, M, D, eps)
+        qkv = ops.linear_fwd(ln1, qkvw, qkvb)
+        ao, lse, cls_row = ops.attn_fwd(qkv, B, n, heads, scale, want_cls)
+        x2d = x.view(M, D)
+        x1 = ops.linear_fwd(ao, projw, projb, epi=ops.EPI_BIAS_RESID, aux=x2d)
+        ln2, mean2, rstd2 = ops.layernorm_fwd(x1, cmap, n2w, n2b, M, D, eps)
+        z = torch.empty((M, fc1w.shape[0]), dtype=torch.float32, device=x.device)
+        h = ops.linear_fwd(ln2, fc1w, fc1b, epi=ops.EPI_BIAS_GELU, aux_out=z)
+        y = ops.linear_fwd(h, fc2w, fc2b, epi=ops.EPI_BIAS_RESID, aux=x1)
+        ctx.save_for_backward(x, n1w, qkvw, projw, n2w, fc1w, fc2w, mean1, rstd1, ln1, qkv, ao, lse, x1, mean2, rstd2, ln2, z, h,
+                              n1b, qkvb, projb, n2b, fc1b, fc2b)
+        ctx.dims = (B, n, D, heads, scale)
+        if cls_row is None:
+            cls_row = torch.empty((0,), device=x.device)
+        ctx.mark_non_differentiable(cls_row)
+        return y.view(B, n, D), cls_row
+
+    @staticmethod
+    def backward(ctx, gy, _gcls):
+        (x, n1w, qkvw, projw, n2w, fc1w, fc2w, mean1, rstd1, ln1, qkv, ao, lse, x1, mean2, rstd2, ln2, z, h,
+         n1b, qkvb, projb, n2b, fc1b, fc2b) = ctx.saved_tensors
+        B, n, D, heads, scale = ctx.dims
+        M = B * n
+        dev = gy.device
+        gy = gy.contiguous().view(M, D)
+        cmap = ops.contiguous_map(M, D)
+        # parameter order: n1w n1b qkvw qkvb projw projb n2w n2b fc1w fc1b fc2w fc2b -> input slots 1..12
+        wants = [_need(ctx, i) for i in range(13)]
+        grads = [None] * 13
+
+        new = ops.grad_buffer
+
+        # ---- MLP branch ----
+        if wants[11]:
+            grads[11] = ops.linear_wgrad(gy, h, new(fc2w))
+        if wants[12]:
+            grads[12] = ops.colsum(gy, new(fc2b))
+        dz = ops.linear_dgrad(gy, fc2w, epi=ops.EPI_MUL_GELU_GRAD, aux=z)
+        if wants[9]:
+            grads[9] = ops.linear_wgrad(dz, ln2, new(fc1w))
+        if wants[10]:
+            grads[10] = ops.colsum(dz, new(fc1b))
+        dln2 = ops.linear_dgrad(dz, fc1w)
+        g1 = torch.empty((M, D), dtype=torch.float32, device=dev)
+        dn2w = new(n2w) if (wants[7] or wants[8]) else None
+        dn2b = new(n2b) if dn2w is not None else None
+        ops.layernorm_bwd(x1, cmap, dln2, n2w, mean2, rstd2, g1, gy, dn2w, dn2b, M, D)
+        grads[7], grads[8] = (dn2w if wants[7] else None), (dn2b if wants[8] else None)
+        # ---- attention branch ----
+        if wants[5]:
+            grads[5] = ops.linear_wgrad(g1, ao, new(projw))
+        if wants[6]:
+            grads[6] = ops.colsum(g1, new(projb))
+        dao = ops.linear_dgrad(g1, projw)
+        dqkv = ops.attn_bwd(qkv, ao, dao, lse, B, n, heads, scale)
+        if wants[3]:
+            grads[3] = ops.linear_wgrad(dqkv, ln1, new(qkvw))
+        if wants[4]:
+            grads[4] = ops.colsum(dqkv, new(qkvb))
+        gx = None
+        if wants[0] or wants[1] or wants[2]:
+            dln1 = ops.linear_dgrad(dqkv, qkvw)
+            gx = torch.empty((M, D), dtype=torch.float32, device=dev)
+            dn1w = new(n1w) if (wants[1] or wants[2]) else None
+            dn1b = new(n1b) if dn1w is not None else None
+            ops.layernorm_bwd(x, cmap, dln1, n1w, mean1, rstd1, gx, g1, dn1w, dn1b, M, D)
+            grads[1], grads[2] = (dn1w if wants[1] else None), (dn1b if wants[2] else None)
+            gx = gx.view(B, n, D) if wants[0] else None
+        grads[0] = gx
+        return tuple(grads) + (None, None, None)
+
+
+class PredictorFn(torch.autograd.Function):
+    """Large LayerNorm predictor (PredictorLG, topk_selection=True) on x[:, 1:] of a [B, n, D] tensor.
+    Returns (scores [B, n-1] differentiable, keep_probs [B, n-1] non-differentiable)."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        # params: in_ln_w, in_ln_b, in_fc_w, in_fc_b, then 5 x (ln_w, ln_b, fc_w, fc_b)
+        B, n, D = x.shape
+        T = n - 1
+        M = B * T
+        x = x.contiguous()
+        eps = 1e-5
+        h0, mean0, rstd0 = ops.layernorm_fwd(x, ops.skip_cls_map(n, D), params[0], params[1], M, D, eps)
+        a1 = ops.linear_fwd(h0, params[2], params[3], epi=ops.EPI_BIAS_RELU)
+        C = a1.shape[1]
+        cur = ops.half_mean_concat(a1, B, T, C)
+        saved = [x, h0, mean0, rstd0, a1]
+        nl = (len(params) - 4) // 4
+        for j in range(nl):
+            lw, lb, fw, fb = params[4 + 4 * j: 8 + 4 * j]
+            width = cur.shape[1]
+            ln, mean, rstd = ops.layernorm_fwd(cur, ops.contiguous_map(M, width), lw, lb, M, width, eps)
+            last = j == nl - 1
+            nxt = ops.linear_fwd(ln, fw, fb, epi=ops.EPI_BIAS if last else ops.EPI_BIAS_RELU)
+            saved += [cur, ln, mean, rstd]
+            cur = nxt
+        scores = cur.view(B, T)
+        probs = ops.softmax_rows(scores)
+        ctx.save_for_backward(*saved, *params)
+        ctx.meta = (B, n, D, T, M, C, nl, len(saved))
+        ctx.mark_non_differentiable(probs)
+        return scores, probs
+
+    @staticmethod
+    def backward(ctx, gscores, _gprobs):
+        B, n, D, T, M, C, nl, nsaved = ctx.meta
+        saved = ctx.saved_tensors[:nsaved]
+        params = ctx.saved_tensors[nsaved:]
+        x, h0, mean0, rstd0, a1 = saved[:5]
+        dev = gscores.device
+        np_ = len(params)
+        grads = [None] * np_
+        want = [_need(ctx, 1 + i) for i in range(np_)]
+        d = gscores.contiguous().view(M, 1)
+        for j in reversed(range(nl)):
+            cur, ln, mean, rstd = saved[5 + 4 * j: 9 + 4 * j]
+            lw, lb, fw, fb = params[4 + 4 * j: 8 + 4 * j]
+            base = 4 + 4 * j
+            width = cur.shape[1]
+            # d is the gradient w.r.t. the pre-activation of layer j's Linear (the ReLU mask was applied upstream)
+            if want[base + 2]:
+                grads[base + 2] = ops.linear_wgrad(d, ln, ops.grad_buffer(fw))
+            if want[base + 3]:
+                grads[base + 3] = ops.colsum(d, ops.grad_buffer(fb))
+            dln = ops.linear_dgrad(d, fw)
+            dcur = torch.empty((M, width), dtype=torch.float32, device=dev)
+            dlw = ops.grad_buffer(lw) if (want[base] or want[base + 1]) else None
+            dlb = ops.grad_buffer(lb) if dlw is not None else None
+            # cur is the ReLU output of layer j-1 for j >= 1 -> fold that ReLU's backward in; for j == 0 cur is the
+            # split/mean/concat output and the mask is applied by half_mean_concat below
+            ops.layernorm_bwd(cur, ops.contiguous_map(M, width), dln, lw, mean, rstd, dcur, None, dlw, dlb, M, width,
+                              relu_mask=(j >= 1))
+            grads[base], grads[base + 1] = (dlw if want[base] else None), (dlb if want[base + 1] else None)
+            d = dcur
+        dz1 = ops.half_mean_concat(d, B, T, C, relu_mask_src=a1)
+        if want[2]:
+            grads[2] = ops.linear_wgrad(dz1, h0, ops.grad_buffer(params[2]))
+        if want[3]:
+            grads[3] = ops.colsum(dz1, ops.grad_buffer(params[3]))
+        gx = None
+        if _need(ctx, 0) or want[0] or want[1]:
+            dh0 = ops.linear_dgrad(dz1, params[2])
+            gx = torch.zeros((B, n, D), dtype=torch.float32, device=dev)
+            dlw = ops.grad_buffer(params[0]) if (want[0] or want[1]) else None
+            dlb = ops.grad_buffer(params[1]) if dlw is not None else None
+            ops.layernorm_bwd(x, ops.skip_cls_map(n, D), dh0, params[0], mean0, rstd0, gx, None, dlw, dlb, M, D)
+            grads[0], grads[1] = (dlw if want[0] else None), (dlb if want[1] else None)
+            if not _need(ctx, 0):
+                gx = None
+        return (gx,) + tuple(grads)
+
+
+class GatherFn(torch.autograd.Function):
+    """Pack the surviving tokens: out[b] = x[b, [0, kept+1]]; backward scatters (zeros for dropped tokens)."""
+
+    @staticmethod
+    def forward(ctx, x, kept):
+        ctx.save_for_backward(kept)
+        ctx.n = x.shape[1]
+        return ops.gather_pack(x.contiguous(), kept)
+
+    @staticmethod
+    def backward(ctx, g):
+        (kept,) = ctx.saved_tensors
+        return ops.scatter_unpack(g.contiguous(), kept, ctx.n), None
+
+
+class HeadFn(torch.autograd.Function):
+    """Final LayerNorm + classifier head on the CLS row.  Returns (logits [B,C], features = normed tokens[:, 1:])."""
+
+    @staticmethod
+    def forward(ctx, x, nw, nb, hw, hb, eps):
+        B, n, D = x.shape
+        M = B * n
+        x = x.contiguous()
+        xn, mean, rstd = ops.layernorm_fwd(x, ops.contiguous_map(M, D), nw, nb, M, D, eps)
+        C = hw.shape[0]
+        logits = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        ops.gemm(ops.NT, xn, n * D, hw, D, logits, C, B, C, D, ops.EPI_BIAS, hb)   # A = CLS rows (row stride n*D)
+        ctx.save_for_backward(x, nw, hw, mean, rstd, xn, nb, hb)
+        ctx.dims = (B, n, D, C)
+        return logits, xn.view(B, n, D)[:, 1:]
+
+    @staticmethod
+    def backward(ctx, glogits, gfeat):
+        x, nw, hw, mean, rstd, xn, nb, hb = ctx.saved_tensors
+        B, n, D, C = ctx.dims
+        M = B * n
+        dev = x.device
+        gfull = torch.zeros((B, n, D), dtype=torch.float32, device=dev)
+        if gfeat is not None and n > 1:
+            gfeat = gfeat.contiguous()
+            ops.copy_rows(gfeat, ops.contiguous_map(B * (n - 1), D), B * (n - 1), D, dst=gfull, dst_map=ops.skip_cls_map(n, D))
+        dhw = dhb = None
+        if glogits is not None:
+            glogits = glogits.contiguous()
+            cls_g = ops.linear_dgrad(glogits, hw)
+            ops.copy_rows(cls_g, ops.contiguous_map(B, D), B, D, dst=gfull, dst_map=(1, n * D, D, 0))
+            if _need(ctx, 3):
+                cls_rows = ops.copy_rows(xn, (1, n * D, D, 0), B, D)
+                dhw = ops.linear_wgrad(glogits, cls_rows, ops.grad_buffer(hw))
+            if _need(ctx, 4):
+                dhb = ops.colsum(glogits, ops.grad_buffer(hb))
+        gx = torch.empty((M, D), dtype=torch.float32, device=dev)
+        dnw = ops.grad_buffer(nw) if (_need(ctx, 1) or _need(ctx, 2)) else None
+        dnb = ops.grad_buffer(nb) if dnw is not None else None
+        ops.layernorm_bwd(x, ops.contiguous_map(M, D), gfull.view(M, D), nw, mean, rstd, gx, None, dnw, dnb, M, D)
+        return (gx.view(B, n, D) if _need(ctx, 0) else None, dnw if _need(ctx, 1) else None, dnb if _need(ctx, 2) else None,
+                dhw, dhb, None)
+
+
+def rows_map_3d(t):
+    """Row map (relative to t.data_ptr()) of a [B, R, C] tensor whose last dim is dense."""
+    assert t.dim() == 3 and t.stride(2) == 1
+    return (t.shape[1], t.stride(0), t.stride(1), 0)
+
+
+class RowLossFn(torch.autograd.Function):
+    """mean-over-`denom` of a per-row loss from d2s_kl_rows: cross entropy, KL between two log-softmaxes, or KL against a
+    probability target (losses.py:94-95,196,198-203,220-225).  Gradient flows to `s` only (the targets are teacher
+    outputs).  `s` is [rows, C] contiguous or a [B, R, C] view with a dense last dim."""
+
+    @staticmethod
+    def forward(ctx, s, mode, t, t_ids, labels, denom):
+        if s.dim() == 3:
+            smap = rows_map_3d(s)
+            rows, C = s.shape[0] * s.shape[1], s.shape[2]
+        else:
+            s = s.contiguous()
+            rows, C = s.shape
+            smap = ops.contiguous_map(rows, C)
+        tmap = (1, 0, 0, 0)
+        tid = None
+        if t is not None:
+            if t_ids is not None:       # teacher tokens gathered by kept ids: row r -> t[b, ids[b, j]]
+                assert t.dim() == 3 and t.stride(2) == 1
+                tmap = (t_ids.shape[1], t.stride(0), t.stride(1), 0)
+                tid = t_ids.contiguous().view(-1)
+            elif t.dim() == 3:
+                tmap = rows_map_3d(t)
+            else:
+                t = t.contiguous()
+                tmap = ops.contiguous_map(rows, C)
+        loss_row, grad = ops.kl_rows(s, smap, rows, C, mode, t=t, t_map=tmap, t_ids=tid, labels=labels, want_grad=True)
+        ctx.save_for_backward(grad)
+        ctx.meta = (tuple(s.shape), float(denom))
+        return ops.sum_scalar(loss_row, 1.0 / float(denom))
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        shape, denom = ctx.meta
+        gs = ops.scale_by_scalar(grad, g.contiguous(), 1.0 / denom)
+        return gs.view(shape), None, None, None, None, None
+
+
+def select_topk(keep_probs, k):
+    """Hard top-k of the keep probabilities (dynamic_vit.py:858-862): (kept, dropped) int64, each ascending."""
+    return ops.select_topk(keep_probs.detach().contiguous(), k)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) for the stand-alone Mlp / Attention modules (act: None | "gelu" | "relu")."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        x = x.contiguous()
+        z = None
+        if act == "gelu":
+            z = torch.empty((x.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
+            y = ops.linear_fwd(x, w, b, epi=ops.EPI_BIAS_GELU, aux_out=z)
+        elif act == "relu":
+            y = ops.linear_fwd(x, w, b, epi=ops.EPI_BIAS_RELU)
+            z = y
+        else:
+            y = ops.linear_fwd(x, w, b)
+        ctx.act = act
+        ctx.save_for_backward(x, w, z if z is not None else x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, z = ctx.saved_tensors
+        g = g.contiguous()
+        if ctx.act == "gelu":     # dz = g * gelu'(z): identity-weight GEMMs are wasteful, so use the elementwise route
+            g = ops.act_grad(g, z, "gelu")
+        elif ctx.act == "relu":
+            g = ops.act_grad(g, z, "relu")
+        dx = ops.linear_dgrad(g, w) if ctx.needs_input_grad[0] else None
+        dw = ops.linear_wgrad(g, x, torch.empty_like(w)) if ctx.needs_input_grad[1] else None
+        db = ops.colsum(g, torch.empty((w.shape[0],), dtype=torch.float32, device=g.device)) if ctx.needs_input_grad[2] else None
+        return dx, dw, db, None
+
+
+class AttnCoreFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dh)) v on the raw qkv Linear output [B*n, 3*H*64] (+ CLS softmax row)."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, n, H, scale, want_cls):
+        qkv = qkv.contiguous()
+        out, lse, cls_row = ops.attn_fwd(qkv, B, n, H, scale, want_cls)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.dims = (B, n, H, scale)
+        if cls_row is None:
+            cls_row = torch.empty((0,), device=qkv.device)
+        ctx.mark_non_differentiable(cls_row)
+        return out, cls_row
+
+    @staticmethod
+    def backward(ctx, g, _gc):
+        qkv, out, lse = ctx.saved_tensors
+        B, n, H, scale = ctx.dims
+        return ops.attn_bwd(qkv, out, g.contiguous(), lse, B, n, H, scale), None, None, None, None, None
+
+
+class PerturbedTopKFn(torch.autograd.Function):
+    """vit_models/peturbed_topk.py:16-80 with the noise tensor as an explicit input."""
+
+    @staticmethod
+    def forward(ctx, x, noise, k, sigma):
+        x, noise = x.contiguous(), noise.contiguous()
+        ind = ops.perturbed_topk_fwd(x, noise, k, sigma)
+        ctx.save_for_backward(x, noise)
+        ctx.meta = (k, float(sigma))
+        return ind
+
+    @staticmethod
+    def backward(ctx, g):
+        x, noise = ctx.saved_tensors
+        k, sigma = ctx.meta
+        return ops.perturbed_topk_bwd(x, noise, g.contiguous(), k, sigma), None, None, None

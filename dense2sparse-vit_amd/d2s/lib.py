@@ -22,7 +22,7 @@ _SIGS = {
     "d2s_colsum_f32": (I, [P, L, I, I, P, I, P, Z]),
     "d2s_layernorm_fwd": (I, [P, L, L, L, L, P, P, P, P, P, L, I, F]),
     "d2s_layernorm_bwd_workspace_bytes": (Z, [L, I]),
-    "d2s_layernorm_bwd": (I, [P, L, L, L, L, P, P, P, P, P, P, P, P, I, L, I, P, Z]),
+    "d2s_layernorm_bwd": (I, [P, L, L, L, L, P, P, P, P, P, P, P, P, I, I, L, I, P, Z]),
     "d2s_softmax_rows": (I, [P, P, I, I]),
     "d2s_select_topk": (I, [P, I, I, I, P, P]),
     "d2s_gather_pack_fwd": (I, [P, P, P, I, I, I, I]),
@@ -31,9 +31,21 @@ _SIGS = {
     "d2s_im2col_patch": (I, [P, P, I, I, I, I, I]),
     "d2s_fill_cls": (I, [P, P, P, I, I, I]),
     "d2s_batch_sum": (I, [P, P, I, L, L, I]),
-    "d2s_copy_rows": (I, [P, L, L, L, L, P, L, I]),
+    "d2s_copy_rows": (I, [P, L, L, L, L, P, L, L, L, L, L, I]),
     "d2s_attn_fwd_f32": (I, [P, P, P, P, I, I, I, F]),
     "d2s_attn_bwd_f32": (I, [P, P, P, P, P, P, I, I, I, F]),
+    "d2s_teacher_target": (I, [P, P, I, I, I, I]),
+    "d2s_gather_renorm": (I, [P, P, P, I, I, I, I]),
+    "d2s_kl_rows": (I, [P, L, L, L, L, P, L, L, L, L, P, P, P, P, L, I, I]),
+    "d2s_sum_scalar": (I, [P, L, F, P]),
+    "d2s_scale_by_scalar": (I, [P, P, F, P, L]),
+    "d2s_mask_agreement": (I, [P, P, I, I, I, P]),
+    "d2s_act_grad": (I, [P, P, P, L, I]),
+    "d2s_perturbed_topk_workspace_bytes": (Z, [I, I, I]),
+    "d2s_perturbed_topk_fwd": (I, [P, P, P, I, I, I, I, F, P, Z]),
+    "d2s_perturbed_topk_bwd": (I, [P, P, P, P, I, I, I, I, F]),
+    "d2s_adamw_chunk_elems": (I, None),
+    "d2s_adamw_step": (I, [P, P, P, P, P, I, F, F, F, I, F]),
 }
 
 _lib = None
@@ -55,7 +67,7 @@ def load():
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
-        fn.argtypes = list(args) + ([P] if res is I else [])
+        fn.argtypes = [] if args is None else list(args) + ([P] if res is I else [])
     _lib = lib
     return lib
 

@@ -95,11 +95,11 @@ def layernorm_fwd(x, rowmap, w, b, rows, D, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(x, rowmap, dy, w, mean, rstd, dx, add_src, dw, db, rows, D, accumulate_wb=False):
+def layernorm_bwd(x, rowmap, dy, w, mean, rstd, dx, add_src, dw, db, rows, D, accumulate_wb=False, relu_mask=False):
     need = lib.query("d2s_layernorm_bwd_workspace_bytes", rows, D)
     ws = workspace(need, dy.device)
     lib.call("d2s_layernorm_bwd", lib.ptr(x), *rowmap, lib.ptr(dy), lib.ptr(w), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dx),
-             lib.ptr(add_src), lib.ptr(dw), lib.ptr(db), int(accumulate_wb), rows, D, lib.ptr(ws), ws.numel())
+             lib.ptr(add_src), lib.ptr(dw), lib.ptr(db), int(accumulate_wb), int(relu_mask), rows, D, lib.ptr(ws), ws.numel())
     return dx
 
 
@@ -164,9 +164,12 @@ def batch_sum(g, out, B, count, image_stride, accumulate=False):
     return out
 
 
-def copy_rows(src, rowmap, rows, D):
-    dst = torch.empty((rows, D), dtype=torch.float32, device=src.device)
-    lib.call("d2s_copy_rows", lib.ptr(src), *rowmap, lib.ptr(dst), rows, D)
+def copy_rows(src, rowmap, rows, D, dst=None, dst_map=None):
+    if dst is None:
+        dst = torch.empty((rows, D), dtype=torch.float32, device=src.device)
+    if dst_map is None:
+        dst_map = contiguous_map(rows, D)
+    lib.call("d2s_copy_rows", lib.ptr(src), *rowmap, lib.ptr(dst), *dst_map, rows, D)
     return dst
 
 
@@ -184,3 +187,98 @@ def attn_bwd(qkv, out, dout, lse, B, n, H, scale):
     lib.call("d2s_attn_bwd_f32", lib.ptr(qkv), lib.ptr(out), lib.ptr(dout), lib.ptr(lse), lib.ptr(dqkv), lib.ptr(delta), B, n, H,
              float(scale))
     return dqkv
+
+
+KL_LOGIT_TARGET, KL_PROB_TARGET, CE_LABEL = 0, 1, 2
+
+
+def teacher_target(cls_attn):
+    B, L, H, n = cls_attn.shape
+    out = torch.empty((B, n - 1), dtype=torch.float32, device=cls_attn.device)
+    lib.call("d2s_teacher_target", lib.ptr(_f32(cls_attn)), lib.ptr(out), B, L, H, n)
+    return out
+
+
+def gather_renorm(target, ids, normalize=True):
+    B, T = target.shape
+    k = ids.shape[1]
+    out = torch.empty((B, k), dtype=torch.float32, device=target.device)
+    lib.call("d2s_gather_renorm", lib.ptr(_f32(target)), lib.ptr(ids), lib.ptr(out), B, T, k, int(normalize))
+    return out
+
+
+def kl_rows(s, s_map, rows, C, mode, t=None, t_map=(1, 0, 0, 0), t_ids=None, labels=None, want_grad=True):
+    loss_row = torch.empty((rows,), dtype=torch.float32, device=s.device)
+    grad = torch.empty((rows, C), dtype=torch.float32, device=s.device) if want_grad else None
+    lib.call("d2s_kl_rows", lib.ptr(s), *s_map, lib.ptr(t), *t_map, lib.ptr(t_ids), lib.ptr(labels), lib.ptr(loss_row),
+             lib.ptr(grad), rows, C, mode)
+    return loss_row, grad
+
+
+def sum_scalar(v, scale=1.0):
+    out = torch.empty((), dtype=torch.float32, device=v.device)
+    lib.call("d2s_sum_scalar", lib.ptr(v), v.numel(), float(scale), lib.ptr(out))
+    return out
+
+
+def scale_by_scalar(x, gscalar, scale=1.0):
+    y = torch.empty_like(x)
+    lib.call("d2s_scale_by_scalar", lib.ptr(x), lib.ptr(gscalar), float(scale), lib.ptr(y), x.numel())
+    return y
+
+
+def mask_agreement(ids_a, ids_b, T):
+    B, k = ids_a.shape
+    out = torch.empty((B,), dtype=torch.float32, device=ids_a.device)
+    lib.call("d2s_mask_agreement", lib.ptr(ids_a) if k else None, lib.ptr(ids_b) if k else None, B, T, k, lib.ptr(out))
+    return out
+
+
+def act_grad(g, z, kind):
+    """g * act'(z) (kind 'gelu': z = pre-activation; 'relu': z = ReLU output)."""
+    out = torch.empty_like(g)
+    lib.call("d2s_act_grad", lib.ptr(g), lib.ptr(z), lib.ptr(out), g.numel(), 0 if kind == "gelu" else 1)
+    return out
+
+
+def perturbed_topk_fwd(x, noise, k, sigma):
+    b, d = x.shape
+    nS = noise.shape[1]
+    ind = torch.empty((b, k, d), dtype=torch.float32, device=x.device)
+    need = lib.query("d2s_perturbed_topk_workspace_bytes", b, k, d)
+    ws = workspace(need, x.device)
+    lib.call("d2s_perturbed_topk_fwd", lib.ptr(x), lib.ptr(noise), lib.ptr(ind), b, nS, d, k, float(sigma), lib.ptr(ws), ws.numel())
+    return ind
+
+
+def perturbed_topk_bwd(x, noise, g, k, sigma):
+    b, d = x.shape
+    nS = noise.shape[1]
+    gx = torch.empty((b, d), dtype=torch.float32, device=x.device)
+    lib.call("d2s_perturbed_topk_bwd", lib.ptr(x), lib.ptr(noise), lib.ptr(g), lib.ptr(gx), b, nS, d, k, float(sigma))
+    return gx
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, desc, n_chunks, beta1, beta2, eps, step, grad_scale=1.0):
+    lib.call("d2s_adamw_step", lib.ptr(params), lib.ptr(grads), lib.ptr(exp_avg), lib.ptr(exp_avg_sq), lib.ptr(desc), n_chunks,
+             float(beta1), float(beta2), float(eps), int(step), float(grad_scale))
+
+
+# ---- gradient-arena registry: parameter storage address -> (flat gradient arena, offset, numel, shape) ----
+_GRAD_BUFFERS = {}
+
+
+def register_grad_buffer(param, grad_view):
+    """Route the gradient of `param` into `grad_view` (a slice of a flat gradient arena, see d2s.engine.ParamArena)."""
+    base = grad_view._base if grad_view._base is not None else grad_view
+    _GRAD_BUFFERS[param.data_ptr()] = (base, grad_view.storage_offset(), grad_view.numel(), tuple(grad_view.shape))
+
+
+def grad_buffer(param):
+    """Tensor to write the gradient of `param` into: a FRESH view of its arena slice when registered (a fresh tensor
+    object lets autograd's AccumulateGrad adopt it without a copy), otherwise a new tensor."""
+    ent = _GRAD_BUFFERS.get(param.data_ptr())
+    if ent is None:
+        return torch.empty_like(param)
+    base, off, numel, shape = ent
+    return base.view(-1)[off:off + numel].view(shape)

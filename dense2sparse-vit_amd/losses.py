@@ -1,0 +1,91 @@
+"""Counterpart of the reference's losses.py: same classes, constructor arguments, forward signatures and metrics keys
+(including the swapped train_token_kl_loss / train_cls_kl_loss keys of losses.py:238-239), computed by HIP kernels.
+
+Differences that are deliberate and documented:
+  * running statistics stay on the device (no .item() per step, losses.py:111,230-233 force a D2H sync every step);
+    metrics values are 0-d tensors, `float(v)` reads them.
+  * only the kl_div mask loss and hard-label cross entropy (mixup off) are on the accelerated path; the reference's bce
+    branch is broken as written (undefined `args` / `self.mask_criterions`, losses.py:57-58).
+"""
+import torch
+
+from d2s import functional as DF
+from d2s import ops
+
+
+class MaskLoss(torch.nn.Module):
+    def __init__(self, args, phase):
+        super().__init__()
+        self.phase = phase
+        self.keep_ratios = args.keep_ratios
+        self.loss_type = args.mask_loss_type
+        if self.loss_type != "kl_div":
+            raise NotImplementedError("only mask_loss_type='kl_div' is on the accelerated hot path (losses.py:75-96)")
+        self.count = 1
+        self.running_loss = 0
+        self.runnings_accs = [0 for _ in self.keep_ratios]
+
+    def forward(self, pred_logits, cls_attn_weights, kept_token_idx, metrics):
+        target = ops.teacher_target(cls_attn_weights.contiguous())             # losses.py:76-79
+        B = target.shape[0]
+        mask_loss = 0
+        mask_accs = [0 for _ in self.keep_ratios]
+        for i in range(len(kept_token_idx)):
+            if i > 0:
+                ratio = self.keep_ratios[i] / self.keep_ratios[i - 1]
+                gt_vals = ops.gather_renorm(target, kept_token_idx[i - 1], normalize=False)   # :84-85
+                target = ops.gather_renorm(target, kept_token_idx[i - 1], normalize=True)     # :89-90
+            else:
+                ratio = self.keep_ratios[i]
+                gt_vals = target
+            T = gt_vals.shape[1]
+            nk = int(T * ratio)                                                               # :132,154
+            with torch.no_grad():
+                gt_ids, _ = ops.select_topk(gt_vals, nk)
+                pm_ids, _ = ops.select_topk(ops.softmax_rows(pred_logits[i].detach().contiguous()), nk)
+                agree = ops.mask_agreement(pm_ids, gt_ids, T)
+                mask_accs[i] = ops.sum_scalar(agree, 1.0 / float(B * T))             # :96
+            mask_loss = mask_loss + DF.RowLossFn.apply(pred_logits[i], ops.KL_PROB_TARGET, target, None, None, B)   # :94-95
+        self.running_loss = self.running_loss + mask_loss.detach()
+        metrics[f"{self.phase}_mask_loss"] = self.running_loss / self.count
+        for i, _ in enumerate(self.keep_ratios):
+            self.runnings_accs[i] = self.runnings_accs[i] + mask_accs[i]
+            metrics[f"{self.phase}_mask_acc_{i}"] = self.runnings_accs[i] / self.count
+        self.count += 1
+        return mask_loss
+
+
+class BackboneLoss(torch.nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        if getattr(args, "mixup", 0.) > 0.:
+            raise NotImplementedError("soft-target cross entropy (mixup) is not on the accelerated hot path")
+        if getattr(args, "patch_score_threshold", None) is not None:
+            raise NotImplementedError("patch_score_threshold path is broken in the reference (losses.py:216-218)")
+        self.patch_score_threshold = None
+        self.count = 1
+        self.running_loss = 0
+        self.running_cls_loss = 0
+        self.running_token_kl_loss = 0
+        self.running_token_dist_loss = 0
+        self.runnings_acc = 0
+
+    def forward(self, logits_s, token_s, logits_t, token_t, kept_token_idx, train_labels, metrics):
+        B = logits_s.shape[0]
+        cls_loss = DF.RowLossFn.apply(logits_s, ops.CE_LABEL, None, None, train_labels.contiguous(), B)          # :196
+        cls_kl_loss = DF.RowLossFn.apply(logits_s, ops.KL_LOGIT_TARGET, logits_t.detach(), None, None, B)       # :198-203
+        rows = token_s.shape[0] * token_s.shape[1]
+        # teacher tokens gathered with the LAST stage's stage-relative ids, exactly like losses.py:212
+        token_kl_loss = DF.RowLossFn.apply(token_s, ops.KL_LOGIT_TARGET, token_t.detach(), kept_token_idx[-1], None, rows)   # :218-225
+        backbone_loss = cls_loss + cls_kl_loss + token_kl_loss
+        self.running_loss = self.running_loss + backbone_loss.detach()
+        self.running_cls_loss = self.running_cls_loss + cls_loss.detach()
+        self.running_token_dist_loss = self.running_token_dist_loss + cls_kl_loss.detach()
+        self.running_token_kl_loss = self.running_token_kl_loss + token_kl_loss.detach()
+        metrics["train_backbone_loss"] = self.running_loss / self.count
+        metrics["train_cls_loss"] = self.running_cls_loss / self.count
+        metrics["train_token_kl_loss"] = self.running_token_dist_loss / self.count      # sic: swapped in the reference
+        metrics["train_cls_kl_loss"] = self.running_token_kl_loss / self.count          # (losses.py:238-239)
+        self.count += 1
+        self.last_terms = (cls_loss.detach(), cls_kl_loss.detach(), token_kl_loss.detach())
+        return backbone_loss

@@ -1,0 +1,426 @@
+"""MI355X-native counterpart of the reference's vit_models/dynamic_vit.py.
+
+Same module-level names, constructor signatures, state-dict keys, forward return tuples and post-forward attributes as
+the reference, so train.py / evaluate.py style callers run unchanged - but every arithmetic
+operation is a hand-written HIP kernel reached through the C ABI (d2s.functional / d2s.ops).  nn.Linear / nn.LayerNorm /
+nn.Conv2d objects are kept purely as parameter containers (they give the reference's state-dict key names); their own
+forward is never called.  There is no CPU path: tensors must live on an MI355X and the library must be built.
+
+Line references are to /root/reference/vit_models/dynamic_vit.py.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from d2s import functional as DF
+from .peturbed_topk import PerturbedTopK
+
+
+def to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+def trunc_normal_(t, std=0.02):
+    return nn.init.trunc_normal_(t, std=std, a=-2.0, b=2.0)
+
+
+def batch_index_select(x, idx):
+    """:39-60 - gather rows per batch element (kept for API parity; the model itself uses GatherFn)."""
+    if x.dim() == 3:
+        B, N, C = x.shape
+        off = torch.arange(B, dtype=torch.long, device=x.device).view(B, 1) * N
+        return x.reshape(B * N, C)[(idx + off).reshape(-1)].reshape(B, idx.size(1), C)
+    if x.dim() == 2:
+        B, N = x.shape
+        off = torch.arange(B, dtype=torch.long, device=x.device).view(B, 1) * N
+        return x.reshape(B * N)[(idx + off).reshape(-1)].reshape(B, idx.size(1))
+    raise NotImplementedError
+
+
+class Mlp(nn.Module):
+    """:159-175."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        assert drop == 0., "dropout is identity at the rates the reference uses (p=0)"
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, out_features)
+
+    def forward(self, x):
+        shape = x.shape
+        h = DF.LinearFn.apply(x.reshape(-1, shape[-1]), self.fc1.weight, self.fc1.bias, "gelu")
+        return DF.LinearFn.apply(h, self.fc2.weight, self.fc2.bias, None).reshape(*shape[:-1], -1)
+
+
+class Attention(nn.Module):
+    """:179-236.  policy / softmax_with_policy (:195-214) belongs to the patch_score_threshold path."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        assert dim % num_heads == 0 and dim // num_heads == 64, "the HIP attention kernels are specialised for head_dim 64"
+        assert attn_drop == 0. and proj_drop == 0.
+        self.num_heads = num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x, policy=None, return_cls_attn=False):
+        if policy is not None:
+            raise NotImplementedError("softmax_with_policy (patch_score_threshold path) is not on the accelerated hot path")
+        B, N, C = x.shape
+        qkv = DF.LinearFn.apply(x.reshape(B * N, C), self.qkv.weight, self.qkv.bias, None)
+        o, cls_row = DF.AttnCoreFn.apply(qkv, B, N, self.num_heads, self.scale, bool(return_cls_attn))
+        o = DF.LinearFn.apply(o, self.proj.weight, self.proj.bias, None).reshape(B, N, C)
+        return (o, cls_row) if return_cls_attn else o
+
+
+class Block(nn.Module):
+    """:240-283.  The whole block (LN, qkv, fused attention, proj+residual, LN, fc1+GELU, fc2+residual) is one Function."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0., drop_path=0.,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        assert drop_path == 0., "DropPath is identity at rate 0 (:249); stochastic depth is not on the hot path"
+        assert qkv_bias, "qkv_bias=True everywhere on the path"
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def forward(self, x, policy=None, return_cls_attn=False):
+        if policy is not None:
+            raise NotImplementedError("policy-masked attention (patch_score_threshold) is not on the accelerated hot path")
+        a, m = self.attn, self.mlp
+        y, cls_row = DF.BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+                                      self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
+                                      a.num_heads, self.norm1.eps, bool(return_cls_attn))
+        return (y, cls_row) if return_cls_attn else y
+
+
+class PatchEmbed(nn.Module):
+    """:286-306."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        img_size, patch_size = to_2tuple(img_size), to_2tuple(patch_size)
+        self.img_size, self.patch_size = img_size, patch_size
+        self.num_patches = (img_size[1] // patch_size[1]) * (img_size[0] // patch_size[0])
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def check(self, x):
+        H, W = x.shape[2], x.shape[3]
+        assert H == self.img_size[0] and W == self.img_size[1], \
+            f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
+
+    def forward(self, x):
+        """Patch tokens without CLS / pos (API parity); the models call EmbedFn which fuses those adds."""
+        self.check(x)
+        D = self.proj.weight.shape[0]
+        T = self.num_patches
+        zeros_pos = torch.zeros((1, T + 1, D), dtype=torch.float32, device=x.device)
+        zeros_cls = torch.zeros((1, 1, D), dtype=torch.float32, device=x.device)
+        return DF.EmbedFn.apply(x, self.proj.weight, self.proj.bias, zeros_cls, zeros_pos, self.patch_size[0])[:, 1:]
+
+
+class BatchNormLayer(nn.Module):
+    """:350-367 (predictor_bn variant).  Parameter container only: the BN predictor is outside the accelerated path."""
+
+    def __init__(self, input_dim=384):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(input_dim)
+
+    def forward(self, x):
+        raise NotImplementedError("--predictor-bn is not on the accelerated hot path (SURVEY 8f.4)")
+
+
+class PredictorLG(nn.Module):
+    """:370-560.  Large LayerNorm variant (:491-531) runs as one Function; keys follow the nn.Sequential positions."""
+
+    def __init__(self, embed_dim=384, topk_selection=False, k=None, small_predictor=False, loss_type="kl_div", use_bn=False):
+        super().__init__()
+        if use_bn:
+            raise NotImplementedError("--predictor-bn is not on the accelerated hot path (SURVEY 8f.4)")
+        if small_predictor:
+            raise NotImplementedError("--small-predictor is not on the accelerated hot path yet (SURVEY 8f.4)")
+        self.small_predictor, self.k, self.topk_selection, self.loss_type = small_predictor, k, topk_selection, loss_type
+        D = embed_dim
+        relu = nn.ReLU()
+        self.in_conv = nn.Sequential(nn.LayerNorm(D), nn.Linear(D, D * 4), relu)
+        self.out_conv = nn.Sequential(
+            nn.LayerNorm(D * 4), nn.Linear(D * 4, D * 2), relu,
+            nn.LayerNorm(D * 2), nn.Linear(D * 2, D), relu,
+            nn.LayerNorm(D), nn.Linear(D, D // 2), relu,
+            nn.LayerNorm(D // 2), nn.Linear(D // 2, D // 4), relu,
+            nn.LayerNorm(D // 4), nn.Linear(D // 4, 1), nn.Flatten(start_dim=-2, end_dim=-1))
+        self.topk = PerturbedTopK(k)
+
+    def _params(self):
+        ps = [self.in_conv[0].weight, self.in_conv[0].bias, self.in_conv[1].weight, self.in_conv[1].bias]
+        for i in (0, 3, 6, 9, 12):
+            ps += [self.out_conv[i].weight, self.out_conv[i].bias, self.out_conv[i + 1].weight, self.out_conv[i + 1].bias]
+        return ps
+
+    def forward_tokens(self, x_with_cls):
+        """Scores for x[:, 1:] of a [B, n, D] tensor, read in place (no slice copy).  -> (scores, keep_probs)."""
+        if not self.topk_selection:
+            return None  # the reference's forward falls through and returns None (:537)
+        if self.loss_type not in ("kl_div", "mse"):
+            raise NotImplementedError("sigmoid scores (bce loss type) are not on the accelerated hot path")
+        return DF.PredictorFn.apply(x_with_cls, *self._params())
+
+    def forward(self, x, policy=None, current_sigma=0.0005, cls_attn=None):
+        """Reference signature: x is the CLS-free token tensor [B, N, D] (:855 passes x[:, 1:])."""
+        B, N, D = x.shape
+        pad = torch.zeros((B, 1, D), dtype=x.dtype, device=x.device)
+        return self.forward_tokens(torch.cat([pad, x], dim=1))
+
+
+class _ViTBase(nn.Module):
+    def _build_trunk(self, img_size, patch_size, in_chans, num_classes, embed_dim, depth, num_heads, mlp_ratio, qkv_bias, qk_scale,
+                     representation_size, drop_rate, attn_drop_rate, drop_path_rate, hybrid_backbone, norm_layer):
+        assert hybrid_backbone is None, "HybridEmbed is not on the hot path"
+        assert representation_size is None, "pre_logits representation layer is unused by the reference's factories"
+        assert drop_rate == 0. and attn_drop_rate == 0. and drop_path_rate == 0., "dropout / drop-path are 0 on the path"
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate,
+                  attn_drop=attn_drop_rate, drop_path=0., norm_layer=norm_layer) for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.pre_logits = nn.Identity()
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+
+    def _init_weights(self, m):
+        """:794-801."""
+        if isinstance(m, nn.Linear):
+            trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token'}
+
+    def get_classifier(self):
+        return self.head
+
+    def reset_classifier(self, num_classes, global_pool=''):
+        self.num_classes = num_classes
+        self.head = nn.Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+
+    def _embed(self, x):
+        self.patch_embed.check(x)
+        return DF.EmbedFn.apply(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.cls_token, self.pos_embed,
+                                self.patch_embed.patch_size[0])
+
+    def _head(self, x):
+        return DF.HeadFn.apply(x, self.norm.weight, self.norm.bias, self.head.weight, self.head.bias, self.norm.eps)
+
+
+class VisionTransformerDiffPruning(_ViTBase):
+    """:642-1015 - the student.  Hard top-k by score (argsort path, :858-862), kept-token gather (:907-912)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=True, qk_scale=None, representation_size=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., hybrid_backbone=None, norm_layer=None,
+                 pruning_loc=None, token_ratio=None, distill=False, attn_selection=False, attn_selection_threshold=0.0,
+                 topk_selection=False, early_exit=False, mean_heads=False, random_drop=False, small_predictor=False,
+                 predictor_loss_type=False, predictor_bn=False, patch_score_threshold=None, init_n=14 * 14):
+        super().__init__()
+        self._build_trunk(img_size, patch_size, in_chans, num_classes, embed_dim, depth, num_heads, mlp_ratio, qkv_bias, qk_scale,
+                          representation_size, drop_rate, attn_drop_rate, drop_path_rate, hybrid_backbone, norm_layer)
+        if patch_score_threshold is not None:
+            raise NotImplementedError("patch_score_threshold (dynamic keep ratio) is broken in the reference (dynamic_vit.py:936, "
+                                      "losses.py:216-218) and not on the accelerated hot path (SURVEY 8f.3)")
+        if early_exit:
+            raise NotImplementedError("early_exit head is not on the hot path")
+        pruning_loc = list(pruning_loc or [])
+        token_ratio = list(token_ratio or [])
+        isz = img_size if isinstance(img_size, int) else img_size[0]
+        psz = patch_size if isinstance(patch_size, int) else patch_size[0]
+        self.score_predictor = nn.ModuleList([
+            PredictorLG(embed_dim, topk_selection=topk_selection, k=int(token_ratio[i] * (isz / psz) ** 2),
+                        small_predictor=small_predictor, loss_type=predictor_loss_type, use_bn=predictor_bn)
+            for i in range(len(pruning_loc))])
+        self.num_kept_tokens = []
+        self.attn_selection, self.attn_selection_threshold = attn_selection, attn_selection_threshold
+        self.topk_selection = topk_selection
+        if self.topk_selection:
+            self.current_sigma = 0.05
+        self.mean_heads, self.random_drop, self.current_score, self.early_exit = mean_heads, random_drop, None, early_exit
+        self.cls_attns = []
+        self.kept_token_indices = None
+        self.dropped_token_indices = None
+        self.pred_logits = []
+        self.patch_score_threshold = patch_score_threshold
+        self.keep_ratios = self.min_keep_ratio = self.avg_keep_ratio = self.max_keep_ratio = None
+        self.unpruned = False
+        self.distill = distill
+        self.pruning_loc, self.token_ratio = pruning_loc, token_ratio
+        # the reference hard-codes init_n = 14*14 (:828,852); exposed so that 384x384 inputs can use int(N * ratio) instead
+        self.init_n = init_n
+        # optional callable(block_index): invoked from autograd when every parameter gradient of block i and of all later
+        # layers is final (d2s.engine uses it to start the bucketed gradient all-reduce while backward continues)
+        self.grad_ready_hook = None
+        trunc_normal_(self.pos_embed, std=.02)
+        trunc_normal_(self.cls_token, std=.02)
+        self.apply(self._init_weights)
+
+    def forward(self, x, stacked_cls_attn_weights=None):
+        x = self._embed(x)                                                  # :816-824
+        self.num_kept_tokens, self.cls_attns, self.pred_logits = [], [], []
+        self.kept_token_indices, self.dropped_token_indices = [], []
+        p_count = 0
+        for i, blk in enumerate(self.blocks):
+            if self.grad_ready_hook is not None and x.requires_grad:
+                x.register_hook(lambda g, i=i, cb=self.grad_ready_hook: (cb(i), None)[1])
+            if i in self.pruning_loc:
+                num_keep_node = int(self.init_n * self.token_ratio[p_count])   # :852
+                pred_logits, pred_score = self.score_predictor[p_count].forward_tokens(x)   # :855
+                kept, dropped = DF.select_topk(pred_score, num_keep_node)     # :858-862
+                self.kept_token_indices.append(kept)
+                self.dropped_token_indices.append(dropped)
+                self.pred_logits.append(pred_logits)
+                x = DF.GatherFn.apply(x, kept)                               # :907-912 / :954-960
+                p_count += 1
+            x, cls_attn = blk(x, return_cls_attn=True)                       # :924 / :985
+            self.cls_attns.append(cls_attn[:, :, 1:])
+        logits, features = self._head(x)                                      # :993-1006
+        if self.training:
+            return logits, features, self.pred_logits, self.kept_token_indices   # :1013
+        return logits, self.cls_attns, self.pred_logits, self.kept_token_indices  # :1015
+
+    def forward_cls_attn(self, x):
+        """:1018-1033."""
+        x = self._embed(x)
+        final = None
+        for i, blk in enumerate(self.blocks):
+            if i == len(self.blocks) - 1:
+                _, final = blk(x, return_cls_attn=True)
+            else:
+                x = blk(x)
+        return final
+
+
+class VisionTransformerTeacher(_ViTBase):
+    """:1036-1176 - dense frozen teacher; every block returns its (detached) CLS row."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=True, qk_scale=None, representation_size=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., hybrid_backbone=None, norm_layer=None):
+        super().__init__()
+        self._build_trunk(img_size, patch_size, in_chans, num_classes, embed_dim, depth, num_heads, mlp_ratio, qkv_bias, qk_scale,
+                          representation_size, drop_rate, attn_drop_rate, drop_path_rate, hybrid_backbone, norm_layer)
+        trunc_normal_(self.pos_embed, std=.02)
+        trunc_normal_(self.cls_token, std=.02)
+        self.apply(self._init_weights)
+
+    def forward_cls_attention(self, x):
+        """:1134-1148."""
+        x = self._embed(x)
+        rows = []
+        for blk in self.blocks:
+            x, cls_attns = blk(x, return_cls_attn=True)
+            rows.append(cls_attns.detach())
+        return torch.stack(rows, dim=1)
+
+    def forward(self, x):
+        """:1150-1176 -> (logits, tokens[B,N,D], cls_attn[B,depth,H,N+1])."""
+        x = self._embed(x)
+        rows = []
+        for blk in self.blocks:
+            x, cls_attns = blk(x, return_cls_attn=True)
+            rows.append(cls_attns.detach())
+        logits, tokens = self._head(x)
+        return logits, tokens, torch.stack(rows, dim=1)
+
+
+def resize_pos_embed(posemb, posemb_new):
+    """:1178-1195 - bilinear resize of the grid part of a position embedding (checkpoint ingestion, host side)."""
+    ntok_new = posemb_new.shape[1] - 1
+    posemb_tok, posemb_grid = posemb[:, :1], posemb[0, 1:]
+    gs_old, gs_new = int(math.sqrt(len(posemb_grid))), int(math.sqrt(ntok_new))
+    posemb_grid = posemb_grid.reshape(1, gs_old, gs_old, -1).permute(0, 3, 1, 2)
+    posemb_grid = F.interpolate(posemb_grid, size=(gs_new, gs_new), mode='bilinear')
+    posemb_grid = posemb_grid.permute(0, 2, 3, 1).reshape(1, gs_new * gs_new, -1)
+    return torch.cat([posemb_tok, posemb_grid], dim=1)
+
+
+def checkpoint_filter_fn(state_dict, model):
+    """:1198-1213."""
+    out = {}
+    if 'model' in state_dict:
+        state_dict = state_dict['model']
+    for k, v in state_dict.items():
+        if 'patch_embed.proj.weight' in k and len(v.shape) < 4:
+            O, I, H, W = model.patch_embed.proj.weight.shape
+            v = v.reshape(O, -1, H, W)
+        elif k == 'pos_embed' and v.shape != model.pos_embed.shape:
+            v = resize_pos_embed(v, model.pos_embed)
+        out[k] = v
+    return out
+
+
+def _load_local(model, checkpoint_path, strict):
+    """The reference's factories download DeiT weights (:1221 ff.); there is no network here, so a local file is
+    the only source.  weights_only=True: nothing from the file is executed."""
+    if checkpoint_path is None:
+        return model
+    sd = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+    missing, unexpected = model.load_state_dict(checkpoint_filter_fn(sd, model), strict=strict)
+    print('# missing keys=', missing)
+    print('# unexpected keys=', unexpected)
+    return model
+
+
+_GEOM = {"tiny": dict(embed_dim=192, num_heads=3), "small": dict(embed_dim=384, num_heads=6), "base": dict(embed_dim=768, num_heads=12)}
+
+
+def _student(size, pruning_locs, keep_ratios, checkpoint_path=None, **kwargs):
+    model = VisionTransformerDiffPruning(patch_size=16, depth=12, mlp_ratio=4, qkv_bias=True, pruning_loc=pruning_locs,
+                                         token_ratio=keep_ratios, distill=True, **_GEOM[size], **kwargs)
+    return _load_local(model, checkpoint_path, strict=False)
+
+
+def _teacher(size, checkpoint_path=None):
+    model = VisionTransformerTeacher(patch_size=16, depth=12, mlp_ratio=4, qkv_bias=True, **_GEOM[size])
+    return _load_local(model, checkpoint_path, strict=True)
+
+
+def dynamic_vit_tiny_patch16_224_student(pruning_locs, keep_ratios, **kwargs):
+    return _student("tiny", pruning_locs, keep_ratios, **kwargs)
+
+
+def dynamic_vit_small_patch16_224_student(pruning_locs, keep_ratios, **kwargs):
+    return _student("small", pruning_locs, keep_ratios, **kwargs)
+
+
+def dynamic_vit_base_patch16_224_student(pruning_locs, keep_ratios, **kwargs):
+    return _student("base", pruning_locs, keep_ratios, **kwargs)
+
+
+def dynamic_vit_tiny_patch16_224_teacher(checkpoint_path=None):
+    return _teacher("tiny", checkpoint_path)
+
+
+def dynamic_vit_small_patch16_224_teacher(checkpoint_path=None):
+    return _teacher("small", checkpoint_path)
+
+
+def dynamic_vit_base_patch16_224_teacher(checkpoint_path=None):
+    return _teacher("base", checkpoint_path)

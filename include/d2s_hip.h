@@ -1,0 +1,119 @@
+/* d2s_hip.h - C ABI of libd2s_hip.so: the MI355X (gfx950) kernels of the dense-to-sparse ViT training path.
+ *
+ * The reference (marc345/Dense2Sparse-ViT) is 100 % Python on top of ATen; it has no native boundary of its own.  Each
+ * entry point below replaces the ATen call(s) made at the cited reference lines (paths relative to the reference
+ * repository root) and is what a ctypes / cffi binding on the reference side would bind (INTEGRATION.md shows it).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors kept alive by the Python wrapper);
+ *   - fp32 data, int64 token ids (`long long`), row-major, innermost dimension dense;
+ *   - every launching function returns 0 on success, D2S_ERR_* (< 0) otherwise; nothing throws, nothing allocates:
+ *     scratch is passed in (`workspace`, sized by the matching *_workspace_bytes query);
+ *   - work is enqueued asynchronously on `stream`; calls on different streams need different workspaces;
+ *   - "row map" = (rows_per_group, group_stride, row_stride, offset): element offset of logical row r is
+ *       (r / rows_per_group) * group_stride + offset + (r % rows_per_group) * row_stride
+ *     which lets a kernel read x[:, 1:] of a [B, n, D] buffer in place (vit_models/dynamic_vit.py:855).
+ */
+#ifndef D2S_HIP_H
+#define D2S_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* d2s_stream_t; /* == hipStream_t */
+
+#define D2S_OK 0
+#define D2S_ERR_ARG (-1)
+#define D2S_ERR_WORKSPACE (-2)
+#define D2S_ERR_LAUNCH (-3)
+
+/* ---- GEMM on the f32-input matrix cores (v_mfma_f32_32x32x2_f32) -----------------------------------------------
+ * Replaces nn.Linear / Conv2d forward and their autograd backward: vit_models/dynamic_vit.py:169-175 (Mlp),
+ * :218,:231 (qkv, proj), :298-305 (patch conv as GEMM), :491-531 (predictor layers), :1006 (head).
+ * layout 0 "NT": C[M,N] = A[M,K] * B[N,K]^T (forward); 1 "NN": C[M,N] = A[M,K] * B[K,N] (dgrad);
+ * layout 2 "TN": C[M,N] = A[K,M]^T * B[K,N] (wgrad; split-K slabs in `workspace`, deterministic combine).
+ * epilogue: 0 none, 1 +bias[n], 2 relu(+bias), 3 gelu(+bias) with pre-activation copy to aux_out, 4 +bias+aux[m][n],
+ *           5 *gelu'(aux[m][n]), 6 *(aux[m][n] > 0), 7 +bias+aux[m % aux_rows][n] (pos_embed add), 8 C += acc.
+ * remap_rows_per_img/remap_skip: output row m goes to m + (m / rows_per_img + 1) * skip (leave room for CLS rows). */
+size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K);
+int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
+                 int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, int aux_rows,
+                 int remap_rows_per_img, int remap_skip, int accumulate, void* workspace, size_t workspace_bytes,
+                 d2s_stream_t stream);
+/* out[n] (+)= sum_m X[m][n]: bias gradients of every Linear. */
+size_t d2s_colsum_workspace_bytes(int M, int N);
+int d2s_colsum_f32(const float* X, long ldx, int M, int N, float* out, int accumulate, void* workspace,
+                   size_t workspace_bytes, d2s_stream_t stream);
+
+/* ---- LayerNorm (vit_models/dynamic_vit.py:245,250,678,993 and the predictor's LayerNorms :491-531) -------------- */
+int d2s_layernorm_fwd(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* w,
+                      const float* b, float* y, float* mean, float* rstd, long rows, int D, float eps, d2s_stream_t stream);
+size_t d2s_layernorm_bwd_workspace_bytes(long rows, int D);
+/* dx[map(r)] = (add_src ? add_src[map(r)] : 0) + mask * dLN/dx; relu_mask folds a preceding ReLU's backward in. */
+int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* dy,
+                      const float* w, const float* mean, const float* rstd, float* dx, const float* add_src, float* dweight,
+                      float* dbias, int accumulate_wb, int relu_mask, long rows, int D, void* workspace,
+                      size_t workspace_bytes, d2s_stream_t stream);
+
+/* ---- fused attention, head dim 64 (vit_models/dynamic_vit.py:218-236; CLS row returned at :234) ------------------
+ * qkv: raw output of the qkv Linear, [B, n, 3, H, 64]; out/dout: [B, n, H*64]; lse, cls_row, delta_ws: [B, H, n]. */
+int d2s_attn_fwd_f32(const float* qkv, float* out, float* lse, float* cls_row, int B, int n, int H, float scale,
+                     d2s_stream_t stream);
+int d2s_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws,
+                     int B, int n, int H, float scale, d2s_stream_t stream);
+
+/* ---- token scoring tail, selection, gather / scatter ------------------------------------------------------------- */
+/* F.softmax(scores, dim=-1), vit_models/dynamic_vit.py:551 */
+int d2s_softmax_rows(const float* scores, float* probs, int rows, int T, d2s_stream_t stream);
+/* argsort(desc)[:k] / [k:] then sort ascending, vit_models/dynamic_vit.py:858-862; ties: lowest index first */
+int d2s_select_topk(const float* probs, int B, int T, int k, long long* kept, long long* dropped, d2s_stream_t stream);
+/* torch.gather(x, 1, [0, kept+1]), vit_models/dynamic_vit.py:907-912 (train) / :954-960 (eval), and its backward */
+int d2s_gather_pack_fwd(const float* x, const long long* ids, float* out, int B, int n, int k, int D, d2s_stream_t stream);
+int d2s_scatter_unpack_bwd(const float* g, const long long* ids, float* dx, int B, int n, int k, int D, d2s_stream_t stream);
+/* split / token-mean / concat of the predictor, vit_models/dynamic_vit.py:540-544 (self-adjoint: also its backward) */
+int d2s_half_mean_concat(const float* x, const float* relu_mask_src, float* out, int B, int T, int C, d2s_stream_t stream);
+
+/* ---- patch embedding helpers (vit_models/dynamic_vit.py:298-306, :820-823) ---------------------------------------- */
+int d2s_im2col_patch(const float* img, float* col, int B, int Cin, int H, int W, int P, d2s_stream_t stream);
+int d2s_fill_cls(const float* cls, const float* pos, float* tokens, int B, int n, int D, d2s_stream_t stream);
+int d2s_batch_sum(const float* g, float* out, int B, long count, long image_stride, int accumulate, d2s_stream_t stream);
+int d2s_copy_rows(const float* src, long rows_per_group, long group_stride, long row_stride, long offset, float* dst,
+                  long d_rows_per_group, long d_group_stride, long d_row_stride, long d_offset, long rows, int D,
+                  d2s_stream_t stream);
+
+/* ---- perturbed top-k (vit_models/peturbed_topk.py:16-80), noise injected ------------------------------------------ */
+size_t d2s_perturbed_topk_workspace_bytes(int b, int k, int d);
+int d2s_perturbed_topk_fwd(const float* x, const float* noise, float* indicators, int b, int nS, int d, int k, float sigma,
+                           void* workspace, size_t workspace_bytes, d2s_stream_t stream);
+int d2s_perturbed_topk_bwd(const float* x, const float* noise, const float* grad_out, float* grad_x, int b, int nS, int d, int k,
+                           float sigma, d2s_stream_t stream);
+
+/* ---- losses (losses.py) -------------------------------------------------------------------------------------------- */
+/* losses.py:76-79: mean over layers, max over heads, drop CLS column, renormalise. cls_attn [B,L,H,n] -> [B,n-1] */
+int d2s_teacher_target(const float* cls_attn, float* target, int B, int L, int H, int n, d2s_stream_t stream);
+/* losses.py:84-90: out[b,j] = in[b,ids[b,j]] (/ row sum when normalize) */
+int d2s_gather_renorm(const float* in, const long long* ids, float* out, int B, int T, int k, int normalize, d2s_stream_t stream);
+/* per-row loss + d/ds: mode 0 KL(logsm(s)||logsm(t)) (losses.py:198-203,220-225), 1 KL with t as probabilities (:94-95),
+ * 2 cross entropy with labels (:196).  t rows: row map plus optional t_ids[r] * t_row_stride (teacher tokens gathered
+ * by the kept ids, losses.py:212). */
+int d2s_kl_rows(const float* s, long s_rpg, long s_gs, long s_rs, long s_off, const float* t, long t_rpg, long t_gs, long t_rs,
+                long t_off, const long long* t_ids, const long long* labels, float* loss_row, float* grad, long rows, int C,
+                int mode, d2s_stream_t stream);
+int d2s_sum_scalar(const float* v, long n, float scale, float* out, d2s_stream_t stream);
+int d2s_scale_by_scalar(const float* x, const float* gscalar, float scale, float* y, long n, d2s_stream_t stream);
+/* losses.py:96,121-164: number of positions on which two top-k masks (as id lists) agree */
+int d2s_mask_agreement(const long long* ids_a, const long long* ids_b, int B, int T, int k, float* agree, d2s_stream_t stream);
+int d2s_act_grad(const float* g, const float* z, float* out, long n, int kind, d2s_stream_t stream);
+
+/* ---- optimiser: torch.optim.AdamW (mask_predictor.py:229-230) over a flat arena, one launch ------------------------ */
+int d2s_adamw_chunk_elems(void);
+int d2s_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const void* chunk_desc, int n_chunks,
+                   float beta1, float beta2, float eps, int step, float grad_scale, d2s_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D2S_HIP_H */

@@ -143,7 +143,7 @@ def block(sd, i, x, cfg, policy=None):
     return x, cls_row
 
 
-def predictor(sd, s, x, cfg):
+def predictor(sd, s, x, cfg, margins=None):
     """PredictorLG.forward with topk_selection=True, vit_models/dynamic_vit.py:536-560.
     Large LN variant :491-531 (ReLU), small LN variant :409-426 (GELU).  nn.LayerNorm default eps 1e-5.
     Returns (scores, keep_probs) each [B, n-1]."""
@@ -152,7 +152,10 @@ def predictor(sd, s, x, cfg):
     act = F.gelu if small else F.relu
     D = cfg["dim"]
     h = F.layer_norm(x, (D,), sd[p + "in_conv.0.weight"], sd[p + "in_conv.0.bias"], 1e-5)
-    h = act(F.linear(h, sd[p + "in_conv.1.weight"], sd[p + "in_conv.1.bias"]))
+    z = F.linear(h, sd[p + "in_conv.1.weight"], sd[p + "in_conv.1.bias"])
+    if margins is not None:
+        margins.append(float(z.detach().abs().min()))
+    h = act(z)
     B, N, C = h.shape
     local_x = h[:, :, :C // 2]
     global_x = torch.mean(h[:, :, C // 2:], dim=1, keepdim=True)
@@ -165,6 +168,8 @@ def predictor(sd, s, x, cfg):
         h = F.layer_norm(h, (w.shape[0],), w, sd[p + f"out_conv.{ln_i}.bias"], 1e-5)
         h = F.linear(h, sd[p + f"out_conv.{fc_i}.weight"], sd[p + f"out_conv.{fc_i}.bias"])
         if j < nl - 1:
+            if margins is not None:
+                margins.append(float(h.detach().abs().min()))
             h = act(h)
     scores = h.flatten(-2, -1)
     if cfg["loss_type"] in ("kl_div", "mse"):
@@ -221,10 +226,11 @@ def student_forward(sd, x, cfg, training=True):
     x = embed_tokens(sd, x, cfg)
     counts = keep_counts(cfg)
     pred_logits, kept_all, dropped_all, probs_all, cls_attns = [], [], [], [], []
-    stage = 0
+    relu_margins = []   # min |pre-activation| of every predictor ReLU: a value at fp32-noise level means the gate (and every
+    stage = 0           # gradient below it) is decided by rounding, which parity tests have to know about
     for i in range(cfg["depth"]):
         if i in cfg["pruning_loc"]:
-            scores, probs = predictor(sd, stage, x[:, 1:], cfg)
+            scores, probs = predictor(sd, stage, x[:, 1:], cfg, relu_margins)
             kept, dropped = select_topk(probs, counts[stage])
             pred_logits.append(scores)
             kept_all.append(kept)
@@ -237,7 +243,7 @@ def student_forward(sd, x, cfg, training=True):
     x = F.layer_norm(x, (cfg["dim"],), sd["norm.weight"], sd["norm.bias"], cfg["ln_eps"])
     features = x[:, 1:]
     logits = F.linear(x[:, 0], sd["head.weight"], sd["head.bias"])
-    aux = dict(dropped=dropped_all, keep_probs=probs_all, cls_attns=cls_attns)
+    aux = dict(dropped=dropped_all, keep_probs=probs_all, cls_attns=cls_attns, relu_margins=relu_margins)
     if training:
         return (logits, features, pred_logits, kept_all), aux
     return (logits, cls_attns, pred_logits, kept_all), aux

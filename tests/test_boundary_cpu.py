@@ -1,0 +1,91 @@
+"""CPU tier: the drop-in boundary.  The C-ABI library loads and exports every symbol include/d2s_hip.h declares; the
+product modules expose the reference's names / constructor signatures / state-dict keys; and the product path refuses to
+run without a GPU instead of silently falling back."""
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+from oracle import d2s_oracle as O
+
+REPO = cases.REPO
+
+
+def test_library_exports_every_declared_symbol():
+    from d2s import lib
+    header = open(os.path.join(REPO, "include", "d2s_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(d2s_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 30
+    handle = lib.load()
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in include/d2s_hip.h but not exported by libd2s_hip.so"
+    assert sorted(lib.exported_symbols()) == declared, "python binding table and header disagree"
+
+
+def test_state_dict_keys_match_reference():
+    """Keys/shapes of the drop-in modules == the oracle's table == the parameter names the reference's own classes
+    produced (recorded in the golden fixture's grad_names)."""
+    import vit_models
+    case = cases.MODEL_CASES["small_3stage"]
+    cfg = case["cfg"]
+    m = vit_models.VisionTransformerDiffPruning(embed_dim=384, depth=12, num_heads=6, mlp_ratio=4, qkv_bias=True,
+                                                pruning_loc=[3, 6, 9], token_ratio=[0.7, 0.5, 0.3], distill=True,
+                                                topk_selection=True, predictor_loss_type="kl_div")
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    want = {k: tuple(s) for k, s in O.student_param_shapes(cfg)}
+    assert got == want
+    ref_names = [str(s) for s in cases.load_golden("model_small_3stage")["grad_names"]]
+    assert [n for n, _ in m.named_parameters()] == ref_names          # same names, same registration order
+    assert sum(p.numel() for p in m.parameters()) == 28549675           # counted on the reference's class
+    t = vit_models.VisionTransformerTeacher(embed_dim=384, depth=12, num_heads=6, mlp_ratio=4, qkv_bias=True)
+    assert {k: tuple(v.shape) for k, v in t.state_dict().items()} == {k: tuple(s) for k, s in O.teacher_param_shapes(cfg)}
+
+
+def test_constructor_signature_matches_reference():
+    import vit_models
+    sig = inspect.signature(vit_models.VisionTransformerDiffPruning.__init__)
+    ref = ["img_size", "patch_size", "in_chans", "num_classes", "embed_dim", "depth", "num_heads", "mlp_ratio", "qkv_bias",
+           "qk_scale", "representation_size", "drop_rate", "attn_drop_rate", "drop_path_rate", "hybrid_backbone", "norm_layer",
+           "pruning_loc", "token_ratio", "distill", "attn_selection", "attn_selection_threshold", "topk_selection", "early_exit",
+           "mean_heads", "random_drop", "small_predictor", "predictor_loss_type", "predictor_bn", "patch_score_threshold"]
+    assert list(sig.parameters)[1:1 + len(ref)] == ref          # dynamic_vit.py:648-653
+    for name in ["VisionTransformerTeacher", "PredictorLG", "Attention", "Block", "Mlp", "PatchEmbed", "BatchNormLayer",
+                 "batch_index_select", "resize_pos_embed", "checkpoint_filter_fn", "PerturbedTopK", "PerturbedTopKFunction",
+                 "dynamic_vit_tiny_patch16_224_student", "dynamic_vit_small_patch16_224_student",
+                 "dynamic_vit_base_patch16_224_student", "dynamic_vit_tiny_patch16_224_teacher",
+                 "dynamic_vit_small_patch16_224_teacher", "dynamic_vit_base_patch16_224_teacher"]:
+        assert hasattr(vit_models, name), name
+
+
+def test_no_cpu_fallback():
+    import vit_models
+    from d2s.lib import D2SError
+    m = vit_models.VisionTransformerTeacher(img_size=32, embed_dim=128, depth=1, num_heads=2, num_classes=10)
+    with pytest.raises(D2SError):
+        m(torch.zeros(1, 3, 32, 32))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(REPO, "dense2sparse-vit_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py") and f != "smoke.py":      # smoke.py is the driver's checker entry, allowed by contract
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f"{f} references the oracle"
+
+
+def test_execution_order_arena_layout():
+    import vit_models
+    from d2s.engine import execution_order
+    m = vit_models.VisionTransformerDiffPruning(img_size=64, embed_dim=128, depth=4, num_heads=2, num_classes=10,
+                                                pruning_loc=[1, 2], token_ratio=[0.05, 0.03], topk_selection=True,
+                                                predictor_loss_type="kl_div")
+    order, starts = execution_order(m)
+    assert order[:2] == ["cls_token", "pos_embed"] and order[-1] == "head.bias"
+    i_pred0 = order.index("score_predictor.0.in_conv.0.weight")
+    assert order.index("blocks.0.mlp.fc2.bias") < i_pred0 < order.index("blocks.1.norm1.weight")
+    assert starts[1] == i_pred0 and starts[0] == order.index("blocks.0.norm1.weight")

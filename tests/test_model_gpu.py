@@ -1,0 +1,238 @@
+"""GPU tier, model level: the drop-in vit_models / losses modules (HIP path, through the C ABI) against the CPU oracle
+and against the fixtures the reference itself produced, on the BASELINE configurations (configs[0] DeiT-Tiny 32x32 keep
+1.0, DeiT-S 224 keep .7 / .5 / 3-stage) and the micro geometry.
+
+Tolerances (fp32 HIP vs fp32 CPU reference; accumulation order differs):
+  kept / dropped ids ........ bit-exact
+  logits, tokens, scores .... rtol 1e-4 (atol 2e-5)         [north_star: "logits/loss within a stated fp tolerance"]
+  scalar losses ............. rtol 2e-5
+  gradient L2 norms ......... rtol 1e-3 ; leading gradient elements rtol 5e-3 ; full-tensor relative L2 error < 3e-3
+                              (12 layers of fp32 backward in a different summation order on both sides)
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+from oracle import d2s_oracle as O
+
+pytestmark = pytest.mark.gpu
+HIP_CASES = [n for n in cases.MODEL_CASES if not cases.MODEL_CASES[n]["cfg"]["small_predictor"]]
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def build_models(case, device):
+    import vit_models
+    cfg = case["cfg"]
+    common = dict(img_size=cfg["img_size"], patch_size=cfg["patch"], embed_dim=cfg["dim"], depth=cfg["depth"],
+                  num_heads=cfg["heads"], mlp_ratio=cfg["mlp_ratio"], qkv_bias=True, num_classes=cfg["num_classes"])
+    student = vit_models.VisionTransformerDiffPruning(pruning_loc=list(cfg["pruning_loc"]), token_ratio=list(cfg["token_ratio"]),
+                                                      distill=True, topk_selection=True, predictor_loss_type=cfg["loss_type"], **common)
+    teacher = vit_models.VisionTransformerTeacher(**common)
+    sd_s, sd_t = cases.make_weights(case)
+    student.load_state_dict({k: _t(v) for k, v in sd_s.items()}, strict=True)
+    teacher.load_state_dict({k: _t(v) for k, v in sd_t.items()}, strict=True)
+    return student.to(device), teacher.to(device), sd_s, sd_t
+
+
+def make_args(cfg):
+    a = types.SimpleNamespace()
+    a.keep_ratios = list(cfg["token_ratio"])
+    a.mask_loss_type = cfg["loss_type"]
+    a.mixup = 0.0
+    a.patch_score_threshold = None
+    a.step = 0
+    return a
+
+
+@pytest.mark.parametrize("name", HIP_CASES)
+def test_train_step_parity(name):
+    from d2s.engine import TrainStep
+    dev = torch.device("cuda:0")
+    case = cases.MODEL_CASES[name]
+    cfg = case["cfg"]
+    g = cases.load_golden("model_" + name)
+    student, teacher, sd_s, sd_t = build_models(case, dev)
+    x, y = _t(cases.make_images(case)), _t(cases.make_labels(case))
+    ts = TrainStep(student, teacher, make_args(cfg), warmup_steps=0)
+    student.train()
+    loss, info = ts.forward_losses(x.to(dev), y.to(dev))
+    ts.opt.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+
+    # oracle on the CPU (same inputs, same weights)
+    osd = {k: _t(v).requires_grad_(True) for k, v in sd_s.items()}
+    ototal, oinfo = O.train_step_losses(osd, {k: _t(v) for k, v in sd_t.items()}, cfg, x, y)
+    ototal.backward()
+
+    # ---- integer outputs: exact, against the oracle AND the reference's own fixture
+    for i, k in enumerate(info["kept"]):
+        assert k.dtype == torch.int64
+        np.testing.assert_array_equal(k.cpu().numpy(), oinfo["kept"][i].numpy())
+        np.testing.assert_array_equal(k.cpu().numpy(), g[f"kept_{i}"])
+        np.testing.assert_array_equal(student.dropped_token_indices[i].cpu().numpy(), g[f"dropped_{i}"])
+    # ---- floating point
+    np.testing.assert_allclose(info["logits_t"].cpu().numpy(), g["logits_t"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(info["cls_attn"].cpu().numpy(), g["cls_attn_t"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(info["logits_s"].detach().cpu().numpy(), g["logits_s"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(info["logits_s"].detach().cpu().numpy(), oinfo["logits_s"].detach().numpy(), rtol=1e-4, atol=2e-5)
+    tok = info["token_s"].detach().cpu()
+    assert list(tok.shape) == list(g["token_s_shape"])
+    np.testing.assert_allclose(tok.numpy(), oinfo["token_s"].detach().numpy(), rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(tok[:, :4, :16].numpy(), g["token_s_slice"], rtol=1e-4, atol=3e-5)
+    for i, pl in enumerate(info["pred_logits"]):
+        np.testing.assert_allclose(pl.detach().cpu().numpy(), g[f"pred_logits_{i}"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(float(info["mask_loss"]), float(g["mask_loss"]), rtol=2e-5)
+    np.testing.assert_allclose(float(info["backbone_loss"]), float(g["backbone_loss"]), rtol=2e-5)
+    np.testing.assert_allclose(float(loss), float(ototal), rtol=2e-5)
+    for i in range(len(cfg["token_ratio"])):
+        np.testing.assert_allclose(float(ts.metrics[f"train_mask_acc_{i}"]), float(g[f"metric_train_mask_acc_{i}"]), atol=2.0 / 196)
+    np.testing.assert_allclose(student.cls_attns[0].cpu().numpy(), g["student_cls_attn_0"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(student.cls_attns[-1].cpu().numpy(), g["student_cls_attn_last"], rtol=1e-4, atol=1e-7)
+    # ---- gradients of every parameter: (a) L2 norm and leading elements vs the reference's own fixture; (b) the full
+    # tensor vs an fp64 run of the oracle - the HIP fp32 result must be as close to the exact gradient as the CPU fp32
+    # reference is (within 4x, floor 2e-4): both are fp32 evaluations with different summation orders
+    sd64 = {k: _t(v).double().requires_grad_(True) for k, v in sd_s.items()}
+    total64, info64 = O.train_step_losses(sd64, {k: _t(v).double() for k, v in sd_t.items()}, cfg, x.double(), y)
+    total64.backward()
+    ids_agree = all(torch.equal(a, b) for a, b in zip(info64["kept"], oinfo["kept"]))
+    # A predictor ReLU whose pre-activation is within fp32 rounding of zero (|z| < 5e-6 on O(1) values) is gated by
+    # rounding noise: whichever way it falls, every gradient below that layer moves by ~1e-3.  small_3stage has one such
+    # unit (|z| = 4.5e-7 in out_conv.4 of predictor 0); the tolerance is widened for such cases and only for them.
+    gate_noise = min(info64["aux"]["relu_margins"]) < 5e-6
+    floor = 5e-3 if gate_noise else 2e-4
+    params = dict(student.named_parameters())
+    worst = 0.0
+    for n, ref_norm, ref_head in zip([str(s) for s in g["grad_names"]], g["grad_norms"], g["grad_heads"]):
+        p = params[n]
+        assert ref_norm >= 0 and p.grad is not None, n
+        gf = p.grad.detach().flatten().cpu()
+        assert p.grad.data_ptr() == ts.arena.grad_views[n].data_ptr(), f"{n}: gradient not written into the arena"
+        # atol: a few gradients are exactly zero in exact arithmetic (e.g. the bias of the last predictor LayerNorm, because
+        # d(KL)/d(scores) sums to zero over the tokens of an image); both sides then hold rounding noise of ~1e-8
+        np.testing.assert_allclose(float(gf.double().norm()), ref_norm, rtol=5e-3 if gate_noise else 1e-3, atol=1e-6, err_msg=n)
+        m = min(8, gf.numel())
+        np.testing.assert_allclose(gf[:m].numpy(), ref_head[:m], rtol=5e-3,
+                                   atol=(2e-2 if gate_noise else 5e-4) * float(np.abs(ref_head[:m]).max()) + 2e-6, err_msg=n)
+        if ids_agree:
+            g64 = sd64[n].grad.flatten()
+            denom = float(g64.norm()) + 1e-12
+            err_hip = float((gf.double() - g64).norm()) / denom
+            err_cpu = float((osd[n].grad.flatten().double() - g64).norm()) / denom
+            if denom > 1e-6:
+                assert err_hip <= max(4.0 * err_cpu, floor), (n, err_hip, err_cpu)
+                worst = max(worst, err_hip)
+    print(f"[{name}] worst relative gradient error vs fp64 oracle: {worst:.2e} (relu gate at noise level: {gate_noise})")
+
+
+@pytest.mark.parametrize("name", ["micro1", "small_3stage"])
+def test_eval_forward_parity(name):
+    dev = torch.device("cuda:0")
+    case = cases.MODEL_CASES[name]
+    g = cases.load_golden("model_" + name)
+    student, teacher, _, _ = build_models(case, dev)
+    student.eval()
+    x = _t(cases.make_images(case)).to(dev)
+    with torch.no_grad():
+        logits, cls_attns, pred_logits, kept = student(x)
+        full = teacher.forward_cls_attention(x)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["eval_logits"], rtol=1e-4, atol=2e-5)
+    assert len(cls_attns) == int(g["eval_n_cls"])
+    assert [list(c.shape) for c in cls_attns] == g["eval_cls_shapes"].tolist()
+    np.testing.assert_allclose(cls_attns[min(3, len(cls_attns) - 1)].cpu().numpy(), g["eval_cls_3"], rtol=1e-4, atol=1e-7)
+    for i, k in enumerate(kept):
+        np.testing.assert_array_equal(k.cpu().numpy(), g[f"eval_kept_{i}"])
+    np.testing.assert_allclose(full.cpu().numpy(), g["cls_attn_t"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("name,warmup", [("micro2", 0), ("micro1", 5), ("tiny32", 0)])
+def test_optimizer_steps_match_oracle(name, warmup):
+    """Three full steps (teacher fwd, student fwd, losses, backward, fused AdamW) vs the oracle's torch.optim.AdamW on the
+    reference's parameter groups; warmup=5 exercises the frozen-backbone epochs (only the predictor trains)."""
+    from d2s.engine import TrainStep
+    dev = torch.device("cuda:0")
+    case = cases.MODEL_CASES[name]
+    cfg = case["cfg"]
+    student, teacher, sd_s, sd_t = build_models(case, dev)
+    x, y = _t(cases.make_images(case)), _t(cases.make_labels(case))
+    hp = dict(lr=5e-4, min_lr=1e-5, weight_decay=0.05, epochs=25, warmup_steps=warmup)
+    ts = TrainStep(student, teacher, make_args(cfg), **hp)
+    st = O.TrainState({k: _t(v) for k, v in sd_s.items()}, {k: _t(v) for k, v in sd_t.items()}, cfg, **hp)
+    for step in range(3):
+        info = ts(x.to(dev), y.to(dev))
+        oinfo = st.step(x, y)
+        np.testing.assert_allclose(float(info["loss"]), float(oinfo["loss"]), rtol=5e-5, err_msg=f"step {step}")
+        for i, k in enumerate(info["kept"]):
+            np.testing.assert_array_equal(k.cpu().numpy(), oinfo["kept"][i].numpy())
+    # Adam divides by sqrt(v): where a gradient element is at rounding-noise level its update is O(lr) with a
+    # noise-determined sign, so a handful of elements may legitimately differ by up to steps * lr; everything else must
+    # agree to rtol 2e-4.  Frozen parameters (warm-up epochs) must be bit-identical to their initial values.
+    for n, p in student.named_parameters():
+        ref = st.sd_s[n].detach().numpy()
+        got = p.detach().cpu().numpy()
+        bad = ~np.isclose(got, ref, rtol=2e-4, atol=2e-6)
+        og = st.sd_s[n].grad
+        noise_only = og is not None and float(og.double().norm()) < 1e-6   # e.g. out_conv.12/13.bias: gradient == 0 exactly
+        if not noise_only:
+            assert bad.mean() <= 2e-4, (n, float(bad.mean()))
+        assert float(np.abs(got - ref).max()) <= 2 * 3 * hp["lr"] * 1.01, n   # both sides may move by lr per step, opposite signs
+        if warmup and not ("predictor" in n):
+            np.testing.assert_array_equal(got, sd_s[n], err_msg=n)
+
+
+@pytest.mark.parametrize("tag", list(cases.PTK_CASES))
+def test_perturbed_topk_parity(tag):
+    from d2s import synth
+    import vit_models
+    dev = torch.device("cuda:0")
+    b, nS, d, k, sigma = cases.PTK_CASES[tag]
+    g = cases.load_golden("perturbed_topk")
+    x = _t(synth.normal(f"ptk/{tag}/x", (b, d), std=1.0, seed=3)).to(dev).requires_grad_(True)
+    noise = _t(g[f"{tag}_noise"]).to(dev)
+    ind = vit_models.PerturbedTopKFunction.apply(x, k, nS, sigma, noise)
+    np.testing.assert_allclose(ind.detach().cpu().numpy(), g[f"{tag}_indicators"], rtol=1e-6, atol=0)   # counts / nS
+    go = _t(synth.normal(f"ptk/{tag}/g", (b, k, d), std=1.0, seed=4)).to(dev)
+    ind.backward(go)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"{tag}_grad_x"], rtol=1e-4, atol=1e-5)
+    # module form, and the property every indicator matrix has: each of the k rows sums to 1
+    m = vit_models.PerturbedTopK(k, num_samples=nS)
+    out = m(x.detach(), current_sigma=sigma, noise=noise)
+    np.testing.assert_allclose(out.sum(dim=-1).cpu().numpy(), np.ones((b, k), np.float32), rtol=1e-6)
+
+
+def test_full_size_properties_deit_small_batch128():
+    """BASELINE configs[1] at full size (DeiT-S 224, keep 0.7 @ block 3, batch 128): size-independent properties -
+    kept ids sorted / unique / in range, kept+dropped partition the tokens, gather o scatter = identity, every keep
+    probability row sums to 1, and the selection is idempotent (re-selecting from the same scores gives the same ids)."""
+    import vit_models
+    from d2s import ops, synth
+    dev = torch.device("cuda:0")
+    B = 128
+    torch.manual_seed(0)
+    student = vit_models.dynamic_vit_small_patch16_224_student([3], [0.7], topk_selection=True, predictor_loss_type="kl_div").to(dev)
+    student.train()
+    x = _t(synth.images(B, 3, 224, seed=0)).to(dev)
+    with torch.no_grad():
+        logits, feats, pred_logits, kept = student(x)
+    assert logits.shape == (B, 1000) and feats.shape == (B, 137, 384) and kept[0].shape == (B, 137)
+    k = kept[0].cpu().numpy()
+    d = student.dropped_token_indices[0].cpu().numpy()
+    assert (np.diff(k, axis=1) > 0).all() and (np.diff(d, axis=1) > 0).all()
+    assert k.min() >= 0 and k.max() < 196
+    for b in range(B):
+        assert sorted(np.concatenate([k[b], d[b]]).tolist()) == list(range(196))
+    probs = ops.softmax_rows(pred_logits[0].contiguous())
+    np.testing.assert_allclose(probs.sum(dim=1).cpu().numpy(), np.ones(B, np.float32), rtol=1e-5)
+    k2, _ = ops.select_topk(probs, 137)
+    np.testing.assert_array_equal(k2.cpu().numpy(), k)
+    tok = torch.randn(B, 197, 384, device=dev)
+    packed = ops.gather_pack(tok, kept[0])
+    back = ops.scatter_unpack(packed, kept[0], 197)
+    np.testing.assert_array_equal(ops.gather_pack(back, kept[0]).cpu().numpy(), packed.cpu().numpy())
+    assert torch.isfinite(logits).all()
