@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/s of the dense-to-sparse ViT step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is exactly train.py:40-57 of the reference: frozen teacher forward, student forward (token scoring, top-k
+selection, kept-token gather, pruned blocks), MaskLoss + BackboneLoss, backward, AdamW update - on one synthetic batch
+resident in HBM.  Workload: DeiT-Small 224x224, single-stage pruning keep_ratio 0.5 at block 3, per-GPU batch 128
+(weak scaling: the global batch is 128 * N), fp32 (the reference computes in fp32).  Prints ONE JSON line on rank 0.
+
+Extra objects on the line:
+  roofline      the dominant kernel (fp32 MFMA GEMM family): algorithmic FLOPs of every launch in the timed region /
+                their HIP-event durations, against the 157.3 TFLOP/s fp32 matrix peak of gfx950.
+  gather        the kept-token gather/pack kernel: algorithmic bytes / HIP-event time, against 8 TB/s.
+  cpu_baseline  the CPU oracle (plain torch fp32 restatement of the reference step, pinned to the reference by
+                tests/golden) timed on this host on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "dense2sparse-vit_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--keep", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events (pure step timing)")
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP events around selected C-ABI launches, recorded on the stream the kernels run on (torch's current stream,
+    which is the stream d2s.lib passes to every entry point)."""
+
+    def __init__(self):
+        self.records = {}   # key -> list of (start, end, work)
+        self.enabled = False
+
+    def wrap(self, ops):
+        timer = self
+        orig_gemm, orig_gather = ops.gemm, ops.gather_pack
+
+        def gemm(layout, A, lda, B, ldb, C, ldc, M, N, K, *a, **kw):
+            if not timer.enabled:
+                return orig_gemm(layout, A, lda, B, ldb, C, ldc, M, N, K, *a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = orig_gemm(layout, A, lda, B, ldb, C, ldc, M, N, K, *a, **kw)
+            e.record()
+            timer.records.setdefault(("gemm_f32", ("NT", "NN", "TN")[layout]), []).append((s, e, 2.0 * M * N * K))
+            return out
+
+        def gather_pack(x, ids):
+            if not timer.enabled:
+                return orig_gather(x, ids)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = orig_gather(x, ids)
+            e.record()
+            B, n, D = x.shape
+            k = ids.shape[1]
+            timer.records.setdefault(("gather_pack", ""), []).append((s, e, B * (2.0 * (k + 1) * D * 4 + 8.0 * k)))
+            return out
+
+        ops.gemm, ops.gather_pack = gemm, gather_pack
+
+    def summary(self):
+        out = {}
+        for key, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            out[key] = dict(launches=len(recs), ms=ms, work=sum(w for _, _, w in recs))
+        return out
+
+
+def build(device, keep, seed=0):
+    import vit_models
+    torch.manual_seed(seed)
+    student = vit_models.dynamic_vit_small_patch16_224_student([3], [keep], topk_selection=True, predictor_loss_type="kl_div")
+    teacher = vit_models.dynamic_vit_small_patch16_224_teacher()
+    return student.to(device), teacher.to(device)
+
+
+def cpu_baseline(keep, batch=32, warm=2, steps=10):
+    """The oracle's full train step (teacher fwd, student fwd, losses, backward, torch.optim.AdamW) on the host CPU."""
+    from oracle import d2s_oracle as O
+    from d2s import synth
+    import numpy as np
+    cfg = O.make_cfg(dim=384, depth=12, heads=6, pruning_loc=(3,), token_ratio=(keep,))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    sd_s = {k: t(v) for k, v in synth.fill_state_dict(O.student_param_shapes(cfg), seed=0).items()}
+    sd_t = {k: t(v) for k, v in synth.fill_state_dict(O.teacher_param_shapes(cfg), seed=1).items()}
+    # the container's CPU share, not the host's core count (oversubscribing OpenMP threads stalls for minutes)
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    threads = max(1, min(threads, int(os.environ.get("D2S_CPU_THREADS", "16"))))
+    torch.set_num_threads(threads)
+    st = O.TrainState(sd_s, sd_t, cfg, lr=5e-4, min_lr=1e-5, weight_decay=0.05, epochs=25, warmup_steps=0)
+    x = torch.randn(batch, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    y = torch.randint(0, 1000, (batch,), generator=torch.Generator().manual_seed(1))
+    for _ in range(warm):
+        st.step(x, y)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st.step(x, y)
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch * steps / dt, 3), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{steps} full train steps of the CPU oracle at batch {batch} (same model/config, fp32), after {warm} warm-up; {dt:.1f} s")
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the d2s path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from d2s import ops, lib
+    from d2s.engine import TrainStep
+    lib.load()
+    timer = KernelTimer()
+    timer.wrap(ops)
+
+    student, teacher = build(device, args.keep)
+    targs = types.SimpleNamespace(keep_ratios=[args.keep], mask_loss_type="kl_div", mixup=0.0, patch_score_threshold=None, step=0)
+    ts = TrainStep(student, teacher, targs, lr=5e-4, min_lr=1e-5, weight_decay=0.05, epochs=25, warmup_steps=0,
+                   distributed=distributed)
+    if distributed:
+        dist.broadcast(ts.arena.params, src=0)
+
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    images = torch.randn((args.batch, 3, 224, 224), device=device, generator=g)
+    labels = torch.randint(0, 1000, (args.batch,), device=device, generator=g)
+
+    log(f"models built on {device}; {args.warmup} warm-up steps")
+    for i in range(args.warmup):
+        ts(images, labels)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = not args.no_kernel_timing
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = ts(images, labels)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    loss = float(info["loss"])
+    log(f"timed region done: {args.steps} steps in {elapsed:.3f} s, loss {loss:.5f}")
+
+    if distributed:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        n_gpus = world
+        imgs = args.batch * n_gpus * args.steps
+        line = {
+            "metric": "training images/s, DeiT-S 224 keep_ratio=0.5 (dense-to-sparse ViT train step, teacher fwd + student fwd/bwd + AdamW)",
+            "value": round(imgs / elapsed, 2), "unit": "images/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (N(0,1) images, uniform labels, random-init weights)",
+            "config": {"workload": f"DeiT-Small 224x224 patch16, 1-stage prune keep_ratio={args.keep} @ block 3 (196->{int(196 * args.keep)} tokens), "
+                                   f"large LN predictor, kl_div mask loss, per-GPU batch {args.batch}",
+                       "global_batch": args.batch * n_gpus, "parallelism": f"dp{n_gpus}", "final_loss": round(loss, 5)},
+        }
+        summ = timer.summary()
+        gemms = {k: v for k, v in summ.items() if k[0] == "gemm_f32"}
+        if gemms:
+            tot_ms = sum(v["ms"] for v in gemms.values())
+            tot_fl = sum(v["work"] for v in gemms.values())
+            dom = max(gemms, key=lambda k: gemms[k]["ms"])
+            ach = gemms[dom]["work"] / (gemms[dom]["ms"] * 1e-3) / 1e12
+            line["roofline"] = {"bound": "mfma", "kernel": f"gemm_f32_kernel<{dom[1]}> (v_mfma_f32_32x32x2_f32)",
+                                "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                                "avg_launch_us": round(1000.0 * gemms[dom]["ms"] / gemms[dom]["launches"], 2),
+                                "launches_per_step": gemms[dom]["launches"] / args.steps,
+                                "all_gemm_layouts": {k[1]: {"TFLOP/s": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                                            "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in gemms.items()},
+                                "gemm_share_of_step": round(tot_ms / (1000.0 * elapsed), 4),
+                                "gemm_family_TFLOP/s": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2)}
+        ga = summ.get(("gather_pack", ""))
+        if ga:
+            gbs = ga["work"] / (ga["ms"] * 1e-3) / 1e9
+            line["gather"] = {"bound": "hbm", "kernel": "gather_pack_kernel", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                              "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                              "bytes_per_launch": ga["work"] / ga["launches"], "avg_launch_us": round(1000.0 * ga["ms"] / ga["launches"], 2)}
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            log("timing the CPU oracle (bounded sample)")
+            line["cpu_baseline"] = cpu_baseline(args.keep)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BK = 16;
 
 enum Epi : int {
     EPI_NONE = 0,
@@ -46,12 +46,13 @@ struct GemmArgs {
     int remap_rows_per_img; int remap_skip;
 };
 
-template <int LAY>
+template <int LAY, int BR>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, int row0, int k0, int rows, int kend,
-                                          int vec, int tid, f32x4 (&r)[2]) {
+                                          int vec, int tid, f32x4 (&r)[BR / 64]) {
+    // BR rows x 16 k per tile = BR*4 float4, BR/64 per thread.
     // rows = valid extent of the row dimension, kend = valid extent of the reduction dimension
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < BR / 64; ++i) {
         const int f = tid + i * 256;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (LAY == 0) {
@@ -68,7 +69,7 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, 
                 }
             }
         } else {
-            const int k = k0 + (f >> 5), row = row0 + (f & 31) * 4;
+            const int k = k0 + f / (BR / 4), row = row0 + (f % (BR / 4)) * 4;
             if (k < kend) {
                 const float* p = P + (long)k * ld + row;
                 if (vec && row + 3 < rows) {
@@ -85,30 +86,31 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, 
     }
 }
 
-template <int LAY>
-__device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const f32x4 (&r)[2]) {
-    // S: [BK][128] floats, element (k,row) at k*128 + (row ^ (((k>>2)&3)<<3))
+template <int LAY, int BR>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const f32x4 (&r)[BR / 64]) {
+    // S: [BK][BR] floats, element (k,row) at k*BR + (row ^ (((k>>2)&3)<<3))
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < BR / 64; ++i) {
         const int f = tid + i * 256;
         if (LAY == 0) {
             const int row = f >> 2, kq = f & 3;
             const int col = row ^ (kq << 3);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) S[(kq * 4 + j) * 128 + col] = r[i][j];
+            for (int j = 0; j < 4; ++j) S[(kq * 4 + j) * BR + col] = r[i][j];
         } else {
-            const int k = f >> 5, row = (f & 31) * 4;
+            const int k = f / (BR / 4), row = (f % (BR / 4)) * 4;
             const int col = row ^ (((k >> 2) & 3) << 3);
-            *reinterpret_cast<f32x4*>(&S[k * 128 + col]) = r[i];
+            *reinterpret_cast<f32x4*>(&S[k * BR + col]) = r[i];
         }
     }
 }
 
-template <int ALAY, int BLAY>
+template <int ALAY, int BLAY, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * 128];
-    float* As = smem;                  // [2][BK][128]
-    float* Bs = smem + 2 * BK * 128;   // [2][BK][128]
+    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;   // 2x2 waves, each MT x NT MFMA tiles of 32x32
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+    float* As = smem;                 // [2][BK][BM]
+    float* Bs = smem + 2 * BK * BM;   // [2][BK][BN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -129,47 +131,48 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     const int kend = min(p.K, kbeg + p.k_per_slice);
     const int nk = (kend - kbeg + BK - 1) / BK;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[2], rb[2];
+    f32x4 ra[BM / 64], rb[BN / 64];
     if (nk > 0) {
-        load_tile<ALAY>(p.A, p.lda, row0, kbeg, p.M, kend, p.vecA, tid, ra);
-        load_tile<BLAY>(p.B, p.ldb, col0, kbeg, p.N, kend, p.vecB, tid, rb);
-        store_tile<ALAY>(As, tid, ra);
-        store_tile<BLAY>(Bs, tid, rb);
+        load_tile<ALAY, BM>(p.A, p.lda, row0, kbeg, p.M, kend, p.vecA, tid, ra);
+        load_tile<BLAY, BN>(p.B, p.ldb, col0, kbeg, p.N, kend, p.vecB, tid, rb);
+        store_tile<ALAY, BM>(As, tid, ra);
+        store_tile<BLAY, BN>(Bs, tid, rb);
     }
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            load_tile<ALAY>(p.A, p.lda, row0, kbeg + (kt + 1) * BK, p.M, kend, p.vecA, tid, ra);
-            load_tile<BLAY>(p.B, p.ldb, col0, kbeg + (kt + 1) * BK, p.N, kend, p.vecB, tid, rb);
+            load_tile<ALAY, BM>(p.A, p.lda, row0, kbeg + (kt + 1) * BK, p.M, kend, p.vecA, tid, ra);
+            load_tile<BLAY, BN>(p.B, p.ldb, col0, kbeg + (kt + 1) * BK, p.N, kend, p.vecB, tid, rb);
         }
-        const float* Ac = As + cur * BK * 128;
-        const float* Bc = Bs + cur * BK * 128;
+        const float* Ac = As + cur * BK * BM;
+        const float* Bc = Bs + cur * BK * BN;
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             const int k = 2 * s + half;
             const int sw = ((k >> 2) & 3) << 3;
-            const float a0 = Ac[k * 128 + ((wm * 64 + l31) ^ sw)];
-            const float a1 = Ac[k * 128 + ((wm * 64 + 32 + l31) ^ sw)];
-            const float b0 = Bc[k * 128 + ((wn * 64 + l31) ^ sw)];
-            const float b1 = Bc[k * 128 + ((wn * 64 + 32 + l31) ^ sw)];
-            acc[0][0] = mfma32(a0, b0, acc[0][0]);
-            acc[0][1] = mfma32(a0, b1, acc[0][1]);
-            acc[1][0] = mfma32(a1, b0, acc[1][0]);
-            acc[1][1] = mfma32(a1, b1, acc[1][1]);
+            float a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = Ac[k * BM + ((wm * WM + i * 32 + l31) ^ sw)];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = Bc[k * BN + ((wn * WN + j * 32 + l31) ^ sw)];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
         }
         if (kt + 1 < nk) {
-            store_tile<ALAY>(As + (cur ^ 1) * BK * 128, tid, ra);
-            store_tile<BLAY>(Bs + (cur ^ 1) * BK * 128, tid, rb);
+            store_tile<ALAY, BM>(As + (cur ^ 1) * BK * BM, tid, ra);
+            store_tile<BLAY, BN>(Bs + (cur ^ 1) * BK * BN, tid, rb);
         }
         __syncthreads();
     }
@@ -178,10 +181,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     float* Cb = p.C + (long)blockIdx.z * p.slab_stride;
     const int epi = (gridDim.z > 1) ? (int)EPI_NONE : p.epi;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n = col0 + wn * 64 + nt * 32 + l31;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = col0 + wn * WN + nt * 32 + l31;
             if (n >= p.N) continue;
             float bias = 0.f;
             if (epi == EPI_BIAS || epi == EPI_BIAS_RELU || epi == EPI_BIAS_GELU || epi == EPI_BIAS_RESID ||
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
                 bias = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = row0 + wm * 64 + mt * 32 + mfma32_row(r, half);
+                const int m = row0 + wm * WM + mt * 32 + mfma32_row(r, half);
                 if (m >= p.M) continue;
                 float v = acc[mt][nt][r];
                 long orow = m;
@@ -255,6 +258,33 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Tile choice.  All workgroups of one launch cost the same, and a CU's matrix pipes are the bottleneck, so the launch
+// lasts ceil(nWG / 256 CUs) "rounds" of one tile's work: pick the tile that minimises rounds * tile area (small
+// penalty for the smaller tiles' extra LDS traffic per MFMA).  N = 384 GEMMs at B*n = 12672 rows go from 58 % CU
+// fill with 128x128 tiles (297 workgroups) to 93 % with 64x64 (1188).
+struct Tile { int bm, bn; float penalty; };
+inline Tile pick_tile(int M, int N) {
+    const Tile cand[4] = {{128, 128, 1.00f}, {128, 64, 1.03f}, {64, 128, 1.03f}, {64, 64, 1.08f}};
+    Tile best = cand[0];
+    float best_cost = 1e30f;
+    for (const Tile& t : cand) {
+        const long nwg = (long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
+        const long rounds = (nwg + 255) / 256;
+        const float cost = (float)rounds * t.bm * t.bn * t.penalty;
+        if (cost < best_cost) { best_cost = cost; best = t; }
+    }
+    return best;
+}
+
+template <int ALAY, int BLAY>
+inline void launch_gemm(const Tile& t, dim3 grid, hipStream_t stream, const GemmArgs& p) {
+    dim3 block(256);
+    if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 128, 128>), grid, block, 0, stream, p);
+    else if (t.bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 128, 64>), grid, block, 0, stream, p);
+    else if (t.bn == 128) hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 64, 128>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 64, 64>), grid, block, 0, stream, p);
+}
+
 }  // namespace
 
 extern "C" {
@@ -262,7 +292,7 @@ extern "C" {
 // Workspace needed by d2s_gemm_f32 for a given problem (only the TN / wgrad layout splits K).
 size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K) {
     if (layout != 2) return 0;
-    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     int slices = (1024 + tiles - 1) / tiles;
     const int max_slices = (K + 255) / 256;
     if (slices > max_slices) slices = max_slices;
@@ -288,7 +318,8 @@ int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb,
     const int alay = layout == 2 ? 1 : 0, blay = layout == 0 ? 0 : 1;
     p.vecA = aligned16(A) && (lda % 4 == 0) && (alay == 0 ? (K % 4 == 0) : (M % 4 == 0));
     p.vecB = aligned16(B) && (ldb % 4 == 0) && (blay == 0 ? (K % 4 == 0) : (N % 4 == 0));
-    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    Tile tile = layout == 2 ? Tile{128, 128, 1.f} : pick_tile(M, N);
+    const int tiles = ((M + tile.bm - 1) / tile.bm) * ((N + tile.bn - 1) / tile.bn);
     int slices = 1;
     if (layout == 2) {
         slices = (1024 + tiles - 1) / tiles;
@@ -313,9 +344,9 @@ int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb,
         p.epi = EPI_ACCUM;
     }
     dim3 grid(tiles, 1, slices), block(256);
-    if (layout == 0) hipLaunchKernelGGL((gemm_f32_kernel<0, 0>), grid, block, 0, stream, p);
-    else if (layout == 1) hipLaunchKernelGGL((gemm_f32_kernel<0, 1>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), grid, block, 0, stream, p);
+    if (layout == 0) launch_gemm<0, 0>(tile, grid, stream, p);
+    else if (layout == 1) launch_gemm<0, 1>(tile, grid, stream, p);
+    else launch_gemm<1, 1>(tile, grid, stream, p);
     if (slices > 1) {
         const long total = (long)M * N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), block, 0, stream,

@@ -177,14 +177,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
 }
 
+// fold the per-block partials: one workgroup per 64 columns of [dweight | dbias]; the 4 waves split the partial
+// index, LDS combines them in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* __restrict__ part, int nblocks, int D,
                                                           float* __restrict__ dw, float* __restrict__ db, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= 2 * D) return;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int k = 0; k < nblocks; ++k) s += part[(long)k * 2 * D + c];
-    float* o = c < D ? dw + c : db + (c - D);
-    *o = accumulate ? *o + s : s;
+    if (c < 2 * D)
+        for (int k = wave; k < nblocks; k += 4) s += part[(long)k * 2 * D + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < 2 * D) {
+        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        float* o = c < D ? dw + c : db + (c - D);
+        *o = accumulate ? *o + t : t;
+    }
 }
 
 inline int pick_nv(int D) {
@@ -197,7 +206,7 @@ inline int pick_nv(int D) {
 }
 inline int bwd_blocks(long rows) {
     long nb = (rows + 31) / 32;
-    if (nb > 1024) nb = 1024;
+    if (nb > 256) nb = 256;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
@@ -259,7 +268,7 @@ int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, lo
     }
 #undef D2S_LN_BWD
     if (dweight)
-        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * D + 255) / 256), block, 0, stream, part, nblocks, D, dweight, dbias,
+        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * D + 63) / 64), block, 0, stream, part, nblocks, D, dweight, dbias,
                            accumulate_wb);
     return d2s_check_launch();
 }
