@@ -1,0 +1,68 @@
+"""Multi-process tier.  CPU: the gradient reducer's bucket logic over gloo, world_size 2.  GPU: two ranks sharing the
+one GPU of the test box (gloo on device tensors) against a single-process run on the concatenated batch."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import cases
+
+
+class _FakeArena:
+    def __init__(self, n, rank):
+        self.total = n
+        self.params = torch.zeros(n)
+        self.grads = torch.arange(n, dtype=torch.float32) * (rank + 1)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from d2s.engine import GradReducer
+    arena = _FakeArena(10000, rank)
+    red = GradReducer(arena, bucket_mb=4096 * 4 / (1 << 20))      # 4096-element buckets
+    launches = []
+    orig = red._launch
+    red._launch = lambda lo: (launches.append((lo, red._hi)), orig(lo))[1]
+    for lo in (9000, 7000, 5000, 2500, 100):                     # backward walks the arena from its end to its start
+        red.ready_from(lo)
+    scale = red.finish()
+    expect = torch.arange(10000, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    ok = torch.equal(arena.grads, expect) and scale == 1.0 / world
+    # buckets: contiguous, non-overlapping, cover [0, total), each >= bucket size except the final flush
+    spans = [(lo, hi) for lo, hi in launches if hi > lo]
+    ok = ok and spans[0][1] == 10000 and spans[-1][0] == 0 and all(spans[i][0] == spans[i + 1][1] for i in range(len(spans) - 1))
+    ok = ok and all(hi - lo >= 4096 for lo, hi in spans[:-1])
+    # second step reuses the reducer
+    arena.grads = torch.ones(10000) * (rank + 1)
+    red.ready_from(5000)
+    red.finish()
+    ok = ok and torch.equal(arena.grads, torch.ones(10000) * sum(r + 1 for r in range(world)))
+    q.put((rank, bool(ok), spans))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, 29517, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+
+
+@pytest.mark.gpu
+def test_two_ranks_match_single_process_on_concatenated_batch():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(cases.REPO, "tools", "ddp_check.py")]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "[ddp_check]" in out.stdout
