@@ -105,6 +105,45 @@ __device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const
     }
 }
 
+template <int EPI, int MT, int NT>
+__device__ __forceinline__ void store_tile_out(const GemmArgs& p, float* __restrict__ Cb, const f32x16 (&acc)[MT][NT], int mbase,
+                                               int nbase, int half) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nbase + nt * 32;
+        if (n >= p.N) continue;
+        float bias = 0.f;
+        if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_ROWADD)
+            bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + mt * 32 + mfma32_row(r, half);
+                if (m >= p.M) continue;
+                float v = acc[mt][nt][r];
+                long orow = m;
+                if (EPI == EPI_BIAS_ROWADD && p.remap_rows_per_img > 0)
+                    orow = (long)m + (long)(m / p.remap_rows_per_img) * p.remap_skip + p.remap_skip;
+                float* cp = Cb + orow * p.ldc + n;
+                if (EPI == EPI_BIAS) v += bias;
+                if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
+                if (EPI == EPI_BIAS_GELU) {
+                    v += bias;
+                    if (p.aux_out) p.aux_out[(long)m * p.ldc + n] = v;
+                    v = gelu_erf(v);
+                }
+                if (EPI == EPI_BIAS_RESID) v += bias + p.aux[(long)m * p.ldaux + n];
+                if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(p.aux[(long)m * p.ldaux + n]);
+                if (EPI == EPI_MUL_RELU_MASK) v = p.aux[(long)m * p.ldaux + n] > 0.f ? v : 0.f;
+                if (EPI == EPI_BIAS_ROWADD) v += bias + p.aux[(long)(m % p.aux_rows) * p.ldaux + n];
+                if (EPI == EPI_ACCUM) v += *cp;
+                *cp = v;
+            }
+        }
+    }
+}
+
 template <int ALAY, int BLAY, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;   // 2x2 waves, each MT x NT MFMA tiles of 32x32
@@ -177,45 +216,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue ----
+    // ---- epilogue: the (wave-uniform) epilogue kind is resolved ONCE, each kind has its own straight-line store loop ----
     float* Cb = p.C + (long)blockIdx.z * p.slab_stride;
     const int epi = (gridDim.z > 1) ? (int)EPI_NONE : p.epi;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = col0 + wn * WN + nt * 32 + l31;
-            if (n >= p.N) continue;
-            float bias = 0.f;
-            if (epi == EPI_BIAS || epi == EPI_BIAS_RELU || epi == EPI_BIAS_GELU || epi == EPI_BIAS_RESID ||
-                epi == EPI_BIAS_ROWADD)
-                bias = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = row0 + wm * WM + mt * 32 + mfma32_row(r, half);
-                if (m >= p.M) continue;
-                float v = acc[mt][nt][r];
-                long orow = m;
-                if (p.remap_rows_per_img > 0) orow = (long)m + (long)(m / p.remap_rows_per_img) * p.remap_skip + p.remap_skip;
-                float* cp = Cb + orow * p.ldc + n;
-                switch (epi) {
-                    case EPI_BIAS: v += bias; break;
-                    case EPI_BIAS_RELU: v = fmaxf(v + bias, 0.f); break;
-                    case EPI_BIAS_GELU:
-                        v += bias;
-                        if (p.aux_out) p.aux_out[(long)m * p.ldc + n] = v;
-                        v = gelu_erf(v);
-                        break;
-                    case EPI_BIAS_RESID: v += bias + p.aux[(long)m * p.ldaux + n]; break;
-                    case EPI_MUL_GELU_GRAD: v *= gelu_erf_grad(p.aux[(long)m * p.ldaux + n]); break;
-                    case EPI_MUL_RELU_MASK: v = p.aux[(long)m * p.ldaux + n] > 0.f ? v : 0.f; break;
-                    case EPI_BIAS_ROWADD: v += bias + p.aux[(long)(m % p.aux_rows) * p.ldaux + n]; break;
-                    case EPI_ACCUM: v += *cp; break;
-                    default: break;
-                }
-                *cp = v;
-            }
-        }
+    const int mbase = row0 + wm * WM, nbase = col0 + wn * WN + l31;
+    switch (epi) {
+        case EPI_BIAS: store_tile_out<EPI_BIAS, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
+        case EPI_BIAS_RELU: store_tile_out<EPI_BIAS_RELU, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
+        case EPI_BIAS_GELU: store_tile_out<EPI_BIAS_GELU, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
+        case EPI_BIAS_RESID: store_tile_out<EPI_BIAS_RESID, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
+        case EPI_MUL_GELU_GRAD: store_tile_out<EPI_MUL_GELU_GRAD, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
+        case EPI_MUL_RELU_MASK: store_tile_out<EPI_MUL_RELU_MASK, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
+        case EPI_BIAS_ROWADD: store_tile_out<EPI_BIAS_ROWADD, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
+        case EPI_ACCUM: store_tile_out<EPI_ACCUM, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
+        default: store_tile_out<EPI_NONE, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
     }
 }
 
@@ -264,7 +278,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // fill with 128x128 tiles (297 workgroups) to 93 % with 64x64 (1188).
 struct Tile { int bm, bn; float penalty; };
 inline Tile pick_tile(int M, int N) {
-    const Tile cand[4] = {{128, 128, 1.00f}, {128, 64, 1.03f}, {64, 128, 1.03f}, {64, 64, 1.08f}};
+    const Tile cand[4] = {{128, 128, 1.00f}, {128, 64, 1.06f}, {64, 128, 1.06f}, {64, 64, 1.10f}};
     Tile best = cand[0];
     float best_cost = 1e30f;
     for (const Tile& t : cand) {
