@@ -420,3 +420,145 @@ class TrainState:
         self.opt.step()
         info["loss"] = total.detach()
         return info
+
+
+# --------------------------------------------------------------------------------------------------
+# T2T path: vit_models/t2t_vit.py, token_performer.py, token_transformer.py,
+# transformer_block.py.  Dropout inside Token_performer (p = 0.1, token_performer.py:13,24) is the
+# identity here: parity is defined for p = 0 / eval mode.
+# --------------------------------------------------------------------------------------------------
+def sinusoid_encoding(n_position, d_hid):
+    """transformer_block.get_sinusoid_encoding, transformer_block.py:78-88 (float64 table -> FloatTensor)."""
+    import numpy as np
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)[None, :]
+    table = pos / np.power(10000, 2 * (j // 2) / d_hid)
+    table[:, 0::2] = np.sin(table[:, 0::2])
+    table[:, 1::2] = np.cos(table[:, 1::2])
+    return torch.FloatTensor(table).unsqueeze(0)
+
+
+def unfold_tokens(x_bchw, k, s, p):
+    """nn.Unfold(k, s, p)(x).transpose(1, 2), t2t_vit.py:85,92,99: [B,C,H,W] -> [B, L, C*k*k]."""
+    return F.unfold(x_bchw, kernel_size=k, stride=s, padding=p).transpose(1, 2)
+
+
+def tokens_to_image(x):
+    """t2t_vit.py:90,97: [B, HW, C] -> [B, C, sqrt(HW), sqrt(HW)]."""
+    B, HW, C = x.shape
+    h = int(math.isqrt(HW))
+    return x.transpose(1, 2).reshape(B, C, h, h)
+
+
+def prm_exp(x, w):
+    """Token_performer.prm_exp, token_performer.py:31-43."""
+    m = w.shape[0]
+    xd = (x * x).sum(dim=-1, keepdim=True).repeat(1, 1, m) / 2
+    wtx = torch.einsum("bti,mi->btm", x, w)
+    return torch.exp(wtx - xd) / math.sqrt(m)
+
+
+def token_performer(sd, pre, x):
+    """Token_performer.forward, token_performer.py:45-59 (emb = in_dim, 1 head, epsilon 1e-8, dropout off)."""
+    emb = sd[pre + "proj.weight"].shape[0]
+    h = F.layer_norm(x, (x.shape[-1],), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], 1e-5)
+    k, q, v = torch.split(F.linear(h, sd[pre + "kqv.weight"], sd[pre + "kqv.bias"]), emb, dim=-1)
+    kp, qp = prm_exp(k, sd[pre + "w"]), prm_exp(q, sd[pre + "w"])
+    D = torch.einsum("bti,bi->bt", qp, kp.sum(dim=1)).unsqueeze(dim=2)
+    kptv = torch.einsum("bin,bim->bnm", v, kp)
+    y = torch.einsum("bti,bni->btn", qp, kptv) / (D.repeat(1, 1, emb) + 1e-8)
+    y = v + F.linear(y, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+    h2 = F.layer_norm(y, (emb,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-5)
+    m = F.linear(F.gelu(F.linear(h2, sd[pre + "mlp.0.weight"], sd[pre + "mlp.0.bias"])), sd[pre + "mlp.2.weight"], sd[pre + "mlp.2.bias"])
+    return y + m
+
+
+def token_transformer(sd, pre, x):
+    """Token_transformer.forward, token_transformer.py:26-60: 1 head of width in_dim, scale dim**-0.5, skip through v."""
+    dim = x.shape[-1]
+    in_dim = sd[pre + "attn.proj.weight"].shape[0]
+    B, N, _ = x.shape
+    h = F.layer_norm(x, (dim,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], 1e-5)
+    qkv = F.linear(h, sd[pre + "attn.qkv.weight"], sd.get(pre + "attn.qkv.bias")).reshape(B, N, 3, 1, in_dim).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    a = ((q @ k.transpose(-2, -1)) * (dim ** -0.5)).softmax(dim=-1)
+    o = (a @ v).transpose(1, 2).reshape(B, N, in_dim)
+    y = v.squeeze(1) + F.linear(o, sd[pre + "attn.proj.weight"], sd[pre + "attn.proj.bias"])
+    h2 = F.layer_norm(y, (in_dim,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-5)
+    m = F.linear(F.gelu(F.linear(h2, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"])), sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    return y + m
+
+
+def t2t_module(sd, x, tokens_type="performer"):
+    """T2T_module.forward, t2t_vit.py:83-104."""
+    stage = token_performer if tokens_type == "performer" else token_transformer
+    pre = "tokens_to_token."
+    t = unfold_tokens(x, 7, 4, 2)
+    t = stage(sd, pre + "attention1.", t)
+    t = unfold_tokens(tokens_to_image(t), 3, 2, 1)
+    t = stage(sd, pre + "attention2.", t)
+    t = unfold_tokens(tokens_to_image(t), 3, 2, 1)
+    return F.linear(t, sd[pre + "project.weight"], sd[pre + "project.bias"])
+
+
+def plain_block(sd, i, x, heads, eps=1e-5, want_cls=False):
+    """transformer_block.Block.forward, transformer_block.py:72-75 (qkv_bias False by default, LayerNorm eps 1e-5)."""
+    p = f"blocks.{i}."
+    D = x.shape[-1]
+    B, n, _ = x.shape
+    h = F.layer_norm(x, (D,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
+    qkv = F.linear(h, sd[p + "attn.qkv.weight"], sd.get(p + "attn.qkv.bias")).reshape(B, n, 3, heads, D // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    a = ((q @ k.transpose(-2, -1)) * ((D // heads) ** -0.5)).softmax(dim=-1)
+    o = (a @ v).transpose(1, 2).reshape(B, n, D)
+    x = x + F.linear(o, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+    h2 = F.layer_norm(x, (D,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps)
+    x = x + F.linear(F.gelu(F.linear(h2, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])), sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    return (x, a[:, :, 0, :]) if want_cls else x
+
+
+def t2t_forward(sd, x, depth, heads, tokens_type="performer"):
+    """T2T_ViT.forward_features + forward, t2t_vit.py:156-179: (logits, [normed output of every block])."""
+    B = x.shape[0]
+    t = t2t_module(sd, x, tokens_type)
+    t = torch.cat((sd["cls_token"].expand(B, -1, -1), t), dim=1) + sd["pos_embed"]
+    D = t.shape[-1]
+    heads_out = []
+    for i in range(depth):
+        t = plain_block(sd, i, t, heads)
+        heads_out.append(F.layer_norm(t, (D,), sd["norm.weight"], sd["norm.bias"], 1e-5))
+    f = F.layer_norm(t, (D,), sd["norm.weight"], sd["norm.bias"], 1e-5)
+    return F.linear(f[:, 0], sd["head.weight"], sd["head.bias"]), heads_out
+
+
+def t2t_param_shapes(img_size, dim, depth, heads, mlp_ratio, num_classes, tokens_type="performer", token_dim=64,
+                     pruning_loc=(), in_chans=3):
+    """State-dict entries of T2T_ViT (t2t_vit.py:106-141) in registration order (+ score predictors for the
+    build-defined pruned student).  pos_embed and the performers' `w` are frozen parameters."""
+    out = [("cls_token", (1, 1, dim)), ("pos_embed", (1, (img_size // 16) ** 2 + 1, dim))]
+    for a, d_in in (("attention1", in_chans * 49), ("attention2", token_dim * 9)):
+        p = f"tokens_to_token.{a}."
+        if tokens_type == "performer":
+            out += [(p + "w", (token_dim // 2, token_dim)), (p + "kqv.weight", (3 * token_dim, d_in)), (p + "kqv.bias", (3 * token_dim,)),
+                    (p + "proj.weight", (token_dim, token_dim)), (p + "proj.bias", (token_dim,)),
+                    (p + "norm1.weight", (d_in,)), (p + "norm1.bias", (d_in,)), (p + "norm2.weight", (token_dim,)), (p + "norm2.bias", (token_dim,)),
+                    (p + "mlp.0.weight", (token_dim, token_dim)), (p + "mlp.0.bias", (token_dim,)),
+                    (p + "mlp.2.weight", (token_dim, token_dim)), (p + "mlp.2.bias", (token_dim,))]
+        else:
+            out += [(p + "norm1.weight", (d_in,)), (p + "norm1.bias", (d_in,)), (p + "attn.qkv.weight", (3 * token_dim, d_in)),
+                    (p + "attn.proj.weight", (token_dim, token_dim)), (p + "attn.proj.bias", (token_dim,)),
+                    (p + "norm2.weight", (token_dim,)), (p + "norm2.bias", (token_dim,)),
+                    (p + "mlp.fc1.weight", (token_dim, token_dim)), (p + "mlp.fc1.bias", (token_dim,)),
+                    (p + "mlp.fc2.weight", (token_dim, token_dim)), (p + "mlp.fc2.bias", (token_dim,))]
+    out += [("tokens_to_token.project.weight", (dim, token_dim * 9)), ("tokens_to_token.project.bias", (dim,))]
+    hid = int(dim * mlp_ratio)
+    for i in range(depth):
+        p = f"blocks.{i}."
+        out += [(p + "norm1.weight", (dim,)), (p + "norm1.bias", (dim,)), (p + "attn.qkv.weight", (3 * dim, dim)),
+                (p + "attn.proj.weight", (dim, dim)), (p + "attn.proj.bias", (dim,)), (p + "norm2.weight", (dim,)), (p + "norm2.bias", (dim,)),
+                (p + "mlp.fc1.weight", (hid, dim)), (p + "mlp.fc1.bias", (hid,)), (p + "mlp.fc2.weight", (dim, hid)), (p + "mlp.fc2.bias", (dim,))]
+    out += [("norm.weight", (dim,)), ("norm.bias", (dim,)), ("head.weight", (num_classes, dim)), ("head.bias", (num_classes,))]
+    if pruning_loc:
+        c = make_cfg(dim=dim, pruning_loc=pruning_loc, token_ratio=(0.5,) * len(pruning_loc))
+        out += [e for e in student_param_shapes(c) if e[0].startswith("score_predictor.")]
+    return out

@@ -88,3 +88,24 @@ def make_selection_probs(N, rows=64):
 
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+# T2T micro geometry: 64x64 image -> 256 -> 64 -> 16 tokens, D = 128, 2 heads, mlp_ratio 3
+T2T_CASE = dict(img_size=64, dim=128, depth=2, heads=2, mlp_ratio=3.0, num_classes=10, batch=2, seed=41)
+
+
+def make_t2t_weights(tokens_type, pruning_loc=()):
+    c = T2T_CASE
+    shapes = O.t2t_param_shapes(c["img_size"], c["dim"], c["depth"], c["heads"], c["mlp_ratio"], c["num_classes"], tokens_type,
+                                pruning_loc=pruning_loc)
+    sd = synth.fill_state_dict(shapes, seed=c["seed"], std=0.02, std_overrides={"score_predictor": 0.08, "tokens_to_token": 0.05})
+    sd = synth.perturb_affine(sd, seed=c["seed"])
+    sd["pos_embed"] = O.sinusoid_encoding((c["img_size"] // 16) ** 2 + 1, c["dim"]).numpy()
+    for k in list(sd):
+        if k.endswith(".w"):   # the performer's frozen random features (token_performer.py:28-29): scale sqrt(m) * orthogonal-ish
+            sd[k] = (synth.normal(k, sd[k].shape, std=1.0, seed=c["seed"]) * 0.7).astype(np.float32)
+    return sd
+
+
+def make_t2t_images():
+    return synth.images(T2T_CASE["batch"], 3, T2T_CASE["img_size"], seed=T2T_CASE["seed"])

@@ -62,6 +62,7 @@ def _install_standins():
     mod("timm.models")
     mod("timm.models.layers", DropPath=DropPath, to_2tuple=to_2tuple, trunc_normal_=nn.init.trunc_normal_)
     mod("timm.models.registry", register_model=lambda f: f)
+    mod("timm.models.helpers", load_pretrained=lambda *a, **k: None)
     mod("timm.loss", SoftTargetCrossEntropy=SoftTargetCrossEntropy)
 
 
@@ -81,6 +82,8 @@ def _load_reference():
     load("vit_models.peturbed_topk", os.path.join(REF, "vit_models", "peturbed_topk.py"))
     dv = load("vit_models.dynamic_vit", os.path.join(REF, "vit_models", "dynamic_vit.py"))
     losses = load("ref_losses", os.path.join(REF, "losses.py"))
+    for f in ("transformer_block", "token_transformer", "token_performer", "t2t_vit"):
+        load("vit_models." + f, os.path.join(REF, "vit_models", f + ".py"))
     return dv, losses, sys.modules["vit_models.peturbed_topk"]
 
 
@@ -280,6 +283,47 @@ def gen_perturbed_topk(ptk):
     print(f"[golden] perturbed_topk: {len(out)} arrays")
 
 
+def gen_t2t():
+    """T2T_ViT (performer and transformer token encoders) at a micro geometry, eval mode (dropout off): per-module outputs,
+    logits, per-block normed outputs and parameter-gradient norms of sum(logits * g)."""
+    import contextlib
+    import io
+    t2t = sys.modules["vit_models.t2t_vit"]
+    out = {}
+    for tt in ("performer", "transformer"):
+        c = cases.T2T_CASE
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = t2t.T2T_ViT(img_size=c["img_size"], tokens_type=tt, embed_dim=c["dim"], depth=c["depth"], num_heads=c["heads"],
+                            mlp_ratio=c["mlp_ratio"], num_classes=c["num_classes"], token_dim=64)
+        sd = cases.make_t2t_weights(tt)
+        own = m.state_dict()
+        assert list(own.keys()) == list(sd.keys()), [k for k in own if k not in sd] + [k for k in sd if k not in own]
+        m.load_state_dict({k: _t(v) for k, v in sd.items()})
+        m.eval()
+        x = _t(cases.make_t2t_images())
+        tok0 = m.tokens_to_token.soft_split0(x).transpose(1, 2)
+        a1 = m.tokens_to_token.attention1(tok0)
+        out[f"{tt}_unfold0"] = _np(tok0)
+        out[f"{tt}_attention1"] = _np(a1)
+        out[f"{tt}_t2t_module"] = _np(m.tokens_to_token(x))
+        logits, heads = m.forward_features(x)[0], None
+        cls_feat, block_heads = m.forward_features(x)
+        logits = m.head(cls_feat)
+        out[f"{tt}_logits"] = _np(logits)
+        out[f"{tt}_block_head_last"] = _np(block_heads[-1])
+        g = _t(synth.normal("t2t/g", tuple(logits.shape), seed=9))
+        m.zero_grad()
+        (logits * g).sum().backward()
+        names, norms = [], []
+        for n_, p_ in m.named_parameters():
+            names.append(n_)
+            norms.append(-1.0 if p_.grad is None else float(p_.grad.double().norm()))
+        out[f"{tt}_grad_names"] = np.array(names)
+        out[f"{tt}_grad_norms"] = np.array(norms)
+    np.savez_compressed(os.path.join(OUT, "t2t.npz"), **out)
+    print(f"[golden] t2t: {len(out)} arrays")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -288,6 +332,7 @@ def main():
     gen_selection()
     gen_perturbed_topk(ptk)
     gen_micro_intermediates(dv)
+    gen_t2t()
     for name in cases.MODEL_CASES:
         gen_model_case(dv, losses, name)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
