@@ -196,6 +196,68 @@ __global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* __restric
     }
 }
 
+// ---- generic scalar path for feature widths that are not a multiple of 4 (T2T stage 1: 3*7*7 = 147) ----
+__global__ __launch_bounds__(256) void ln_fwd_scalar_kernel(const float* __restrict__ x, RowMap xm, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            long rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + map_row(xm, row);
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int c = lane; c < D; c += 64) { const float d = xr[c] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    for (int c = lane; c < D; c += 64) y[row * D + c] = (xr[c] - mean) * rstd * w[c] + b[c];
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+}
+
+// one workgroup per chunk of rows; dweight / dbias partials per block via per-thread column ownership (column c is
+// always handled by lane c % 64 of every wave, so the four waves' sums are combined through LDS)
+__global__ __launch_bounds__(256) void ln_bwd_scalar_kernel(const float* __restrict__ x, RowMap xm, const float* __restrict__ dy,
+                                                            const float* __restrict__ w, const float* __restrict__ mean_in,
+                                                            const float* __restrict__ rstd_in, float* __restrict__ dx,
+                                                            const float* __restrict__ add_src, float* __restrict__ part, long rows,
+                                                            int D, long rows_per_block, int relu_mask) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int c = lane; c < 2 * D; c += 64) red[wave * 2 * D + c] = 0.f;
+    for (long row = r0 + wave; row < r1; row += 4) {
+        const long off = map_row(xm, row);
+        const float* xr = x + off;
+        const float* gr = dy + row * D;
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const float xh = (xr[c] - mean) * rstd, gw = gr[c] * w[c];
+            s1 += gw;
+            s2 += gw * xh;
+            red[(wave * 2 + 0) * D + c] += gr[c] * xh;
+            red[(wave * 2 + 1) * D + c] += gr[c];
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+        for (int c = lane; c < D; c += 64) {
+            const float xv = xr[c], xh = (xv - mean) * rstd;
+            float o = rstd * (gr[c] * w[c] - s1 - xh * s2);
+            if (relu_mask && !(xv > 0.f)) o = 0.f;
+            if (add_src) o += add_src[off + c];
+            dx[off + c] = o;
+        }
+    }
+    __syncthreads();
+    if (part)
+        for (int c = threadIdx.x; c < 2 * D; c += 256)
+            part[(long)blockIdx.x * 2 * D + c] = (red[c] + red[2 * D + c]) + (red[4 * D + c] + red[6 * D + c]);
+}
+
 inline int pick_nv(int D) {
     const int nvec = D / 4;
     if (nvec <= 64) return 1;
@@ -220,10 +282,13 @@ extern "C" {
 // Contiguous [rows, D]: rows_per_group = rows, group_stride = 0, row_stride = D, offset = 0.
 int d2s_layernorm_fwd(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* w,
                       const float* b, float* y, float* mean, float* rstd, long rows, int D, float eps, hipStream_t stream) {
-    if (!x || !w || !b || !y || rows <= 0 || D <= 0 || (D & 3) || D > 4096 || rows_per_group <= 0) return D2S_ERR_ARG;
-    if ((group_stride | row_stride | offset) & 3) return D2S_ERR_ARG;
+    if (!x || !w || !b || !y || rows <= 0 || D <= 0 || D > 4096 || rows_per_group <= 0) return D2S_ERR_ARG;
     RowMap m{rows_per_group, group_stride, row_stride, offset};
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if ((D & 3) || ((group_stride | row_stride | offset) & 3)) {
+        hipLaunchKernelGGL(ln_fwd_scalar_kernel, grid, block, 0, stream, x, m, w, b, y, mean, rstd, rows, D, eps);
+        return d2s_check_launch();
+    }
     switch (pick_nv(D)) {
         case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, stream, x, m, w, b, y, mean, rstd, rows, D, eps); break;
         case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, x, m, w, b, y, mean, rstd, rows, D, eps); break;
@@ -244,8 +309,8 @@ int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, lo
                       const float* w, const float* mean, const float* rstd, float* dx, const float* add_src, float* dweight,
                       float* dbias, int accumulate_wb, int relu_mask, long rows, int D, void* workspace,
                       size_t workspace_bytes, hipStream_t stream) {
-    if (!x || !dy || !w || !mean || !rstd || !dx || rows <= 0 || D <= 0 || (D & 3) || D > 4096) return D2S_ERR_ARG;
-    if ((group_stride | row_stride | offset) & 3) return D2S_ERR_ARG;
+    if (!x || !dy || !w || !mean || !rstd || !dx || rows <= 0 || D <= 0 || D > 4096) return D2S_ERR_ARG;
+    const bool scalar = (D & 3) || ((group_stride | row_stride | offset) & 3);
     const int nb = bwd_blocks(rows);
     float* part = nullptr;
     if (dweight) {
@@ -258,6 +323,14 @@ int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, lo
     const int nblocks = (int)((rows + rpb - 1) / rpb);
     dim3 grid(nblocks), block(256);
     const size_t sh = (size_t)3 * 2 * D * sizeof(float);
+    if (scalar) {
+        hipLaunchKernelGGL(ln_bwd_scalar_kernel, grid, block, (size_t)4 * 2 * D * sizeof(float), stream, x, m, dy, w, mean, rstd, dx,
+                           add_src, part, rows, D, rpb, relu_mask);
+        if (dweight)
+            hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * D + 63) / 64), block, 0, stream, part, nblocks, D, dweight, dbias,
+                               accumulate_wb);
+        return d2s_check_launch();
+    }
 #define D2S_LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, sh, stream, x, m, dy, w, mean, rstd, dx, m, add_src, part, rows, D, rpb, relu_mask)
     switch (pick_nv(D)) {
         case 1: D2S_LN_BWD(1); break;

@@ -240,11 +240,31 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict_
     (void)per_image;
 }
 
+// out[b,0,:] = cls + pos[0];  out[b,1+t,:] = tok[b,t,:] + pos[1+t,:]   (t2t_vit.py:160-162: cat CLS, add pos_embed)
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __restrict__ tok, const float* __restrict__ cls,
+                                                              const float* __restrict__ pos, float* __restrict__ out, int T, int D,
+                                                              long total_vec) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;   // float4 index over [B, T+1, D]
+    if (e >= total_vec) return;
+    const int nvec = D >> 2;
+    const int c = (int)(e % nvec);
+    const long r = e / nvec;
+    const int t = (int)(r % (T + 1));
+    const long b = r / (T + 1);
+    const f32x4 pv = reinterpret_cast<const f32x4*>(pos)[(long)t * nvec + c];
+    const f32x4 sv = t == 0 ? reinterpret_cast<const f32x4*>(cls)[c]
+                            : reinterpret_cast<const f32x4*>(tok)[((long)b * T + (t - 1)) * nvec + c];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = sv[j] + pv[j];
+    reinterpret_cast<f32x4*>(out)[e] = o;
+}
+
 // generic row copy through a row map (strip the CLS rows of a gradient buffer, etc.)
 __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, long rows_per_group, long group_stride,
                                                         long row_stride, long offset, float* __restrict__ dst,
                                                         long d_rows_per_group, long d_group_stride, long d_row_stride,
-                                                        long d_offset, long rows, int D) {
+                                                        long d_offset, long rows, int D, int accumulate) {
     const int nvec = D >> 2;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= rows * nvec) return;
@@ -254,7 +274,12 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
     const float* s = src + g * group_stride + offset + t * row_stride;
     const long dg = r / d_rows_per_group, dt = r - dg * d_rows_per_group;
     float* d = dst + dg * d_group_stride + d_offset + dt * d_row_stride;
-    reinterpret_cast<f32x4*>(d)[c] = reinterpret_cast<const f32x4*>(s)[c];
+    f32x4 v = reinterpret_cast<const f32x4*>(s)[c];
+    if (accumulate) {
+        const f32x4 o = reinterpret_cast<const f32x4*>(d)[c];
+        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+    }
+    reinterpret_cast<f32x4*>(d)[c] = v;
 }
 
 }  // namespace
@@ -320,15 +345,24 @@ int d2s_batch_sum(const float* g, float* out, int B, long count, long image_stri
     return d2s_check_launch();
 }
 
+int d2s_assemble_tokens(const float* tok, const float* cls, const float* pos, float* out, int B, int T, int D, hipStream_t stream) {
+    if (!tok || !cls || !pos || !out || B <= 0 || T <= 0 || D <= 0 || (D & 3)) return D2S_ERR_ARG;
+    const long total_vec = (long)B * (T + 1) * (D >> 2);
+    hipLaunchKernelGGL(assemble_tokens_kernel, dim3((unsigned)((total_vec + 255) / 256)), dim3(256), 0, stream, tok, cls, pos, out, T, D,
+                       total_vec);
+    return d2s_check_launch();
+}
+
 // row r of src (through the source row map) -> row r of dst (through the destination row map)
 int d2s_copy_rows(const float* src, long rows_per_group, long group_stride, long row_stride, long offset, float* dst,
                   long d_rows_per_group, long d_group_stride, long d_row_stride, long d_offset, long rows, int D,
-                  hipStream_t stream) {
+                  int accumulate, hipStream_t stream) {
     if (!src || !dst || rows <= 0 || D <= 0 || (D & 3) || rows_per_group <= 0 || d_rows_per_group <= 0) return D2S_ERR_ARG;
     if ((group_stride | row_stride | offset | d_group_stride | d_row_stride | d_offset) & 3) return D2S_ERR_ARG;
     const long total = rows * (D >> 2);
     hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, rows_per_group,
-                       group_stride, row_stride, offset, dst, d_rows_per_group, d_group_stride, d_row_stride, d_offset, rows, D);
+                       group_stride, row_stride, offset, dst, d_rows_per_group, d_group_stride, d_row_stride, d_offset, rows, D,
+                       accumulate);
     return d2s_check_launch();
 }
 

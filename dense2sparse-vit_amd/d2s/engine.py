@@ -123,7 +123,7 @@ class FusedAdamW:
             p.grad = None
 
 
-def adjust_learning_rate(optimizer, model, step, epochs, lr, min_lr, warmup_steps):
+def adjust_learning_rate(optimizer, model, step, epochs, lr, min_lr, warmup_steps, frozen=()):
     """utils.adjust_learning_rate (utils.py:93-147): cosine schedule, backbone frozen for the first `warmup_steps`
     epochs (requires_grad toggled exactly like the reference), backbone lr = min(0.01 lr, cos) afterwards."""
     cos_lr = (math.cos(step / epochs * math.pi) + 1) * 0.5
@@ -131,6 +131,8 @@ def adjust_learning_rate(optimizer, model, step, epochs, lr, min_lr, warmup_step
     predictor_lr = cos_lr
     backbone_lr = 0.0 if step < warmup_steps else min(lr * 0.01, cos_lr)
     for n, p in model.named_parameters():
+        if n in frozen:     # frozen by construction (T2T's sinusoid pos_embed, the performer's random features): never trained
+            continue
         is_pred = "dist" in n or "predictor" in n
         g = _group_of(n, p)
         if g is None:                       # cls_token / pos_embed: in no param group, follow the first loop of the reference
@@ -227,12 +229,13 @@ class TrainStep:
         self.reducer = GradReducer(self.arena, bucket_mb=bucket_mb) if distributed else None
         if self.reducer is not None:
             student.grad_ready_hook = lambda i: self.reducer.ready_from(self.block_offset[i])
+        self.frozen = frozenset(n for n, p in student.named_parameters() if not p.requires_grad)
         self.set_epoch(0)
 
     def set_epoch(self, epoch):
         self.epoch = epoch
         self.args.step = epoch
-        return adjust_learning_rate(self.opt, self.student, epoch, self.epochs, self.lr, self.min_lr, self.warmup_steps)
+        return adjust_learning_rate(self.opt, self.student, epoch, self.epochs, self.lr, self.min_lr, self.warmup_steps, self.frozen)
 
     def forward_losses(self, images, labels):
         with torch.no_grad():

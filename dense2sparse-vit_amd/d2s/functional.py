@@ -333,6 +333,31 @@ class RowLossFn(torch.autograd.Function):
         return gs.view(shape), None, None, None, None, None
 
 
+class AddClsPosFn(torch.autograd.Function):
+    """tokens [B,T,D] -> [B,T+1,D]: prepend the CLS token and add the position table (t2t_vit.py:160-162)."""
+
+    @staticmethod
+    def forward(ctx, tok, cls_token, pos_embed):
+        B, T, D = tok.shape
+        out = torch.empty((B, T + 1, D), dtype=torch.float32, device=tok.device)
+        lib_call = ops.lib.call
+        lib_call("d2s_assemble_tokens", ops.lib.ptr(tok.contiguous()), ops.lib.ptr(cls_token), ops.lib.ptr(pos_embed), ops.lib.ptr(out),
+                 B, T, D)
+        ctx.save_for_backward(cls_token, pos_embed)
+        ctx.dims = (B, T, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cls_token, pos_embed = ctx.saved_tensors
+        B, T, D = ctx.dims
+        g = g.contiguous()
+        dtok = ops.copy_rows(g, ops.skip_cls_map(T + 1, D), B * T, D).view(B, T, D) if ctx.needs_input_grad[0] else None
+        dcls = ops.batch_sum(g, ops.grad_buffer(cls_token), B, D, (T + 1) * D) if ctx.needs_input_grad[1] else None
+        dpos = ops.batch_sum(g, ops.grad_buffer(pos_embed), B, (T + 1) * D, (T + 1) * D) if ctx.needs_input_grad[2] else None
+        return dtok, dcls, dpos
+
+
 def select_topk(keep_probs, k):
     """Hard top-k of the keep probabilities (dynamic_vit.py:858-862): (kept, dropped) int64, each ascending."""
     return ops.select_topk(keep_probs.detach().contiguous(), k)

@@ -31,7 +31,13 @@ _SIGS = {
     "d2s_im2col_patch": (I, [P, P, I, I, I, I, I]),
     "d2s_fill_cls": (I, [P, P, P, I, I, I]),
     "d2s_batch_sum": (I, [P, P, I, L, L, I]),
-    "d2s_copy_rows": (I, [P, L, L, L, L, P, L, L, L, L, L, I]),
+    "d2s_copy_rows": (I, [P, L, L, L, L, P, L, L, L, L, L, I, I]),
+    "d2s_assemble_tokens": (I, [P, P, P, P, I, I, I]),
+    "d2s_unfold_fwd": (I, [P, L, L, L, L, P, I, I, I, I, I, I, I]),
+    "d2s_unfold_bwd": (I, [P, P, L, L, L, L, I, I, I, I, I, I, I]),
+    "d2s_performer_workspace_bytes": (Z, [I, I]),
+    "d2s_performer_attn_fwd": (I, [P, P, P, P, P, P, P, P, I, I, F, P, Z]),
+    "d2s_performer_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, F, P, Z]),
     "d2s_attn_fwd_f32": (I, [P, P, P, P, I, I, I, F]),
     "d2s_attn_bwd_f32": (I, [P, P, P, P, P, P, I, I, I, F]),
     "d2s_teacher_target": (I, [P, P, I, I, I, I]),

@@ -164,13 +164,49 @@ def batch_sum(g, out, B, count, image_stride, accumulate=False):
     return out
 
 
-def copy_rows(src, rowmap, rows, D, dst=None, dst_map=None):
+def copy_rows(src, rowmap, rows, D, dst=None, dst_map=None, accumulate=False):
     if dst is None:
         dst = torch.empty((rows, D), dtype=torch.float32, device=src.device)
     if dst_map is None:
         dst_map = contiguous_map(rows, D)
-    lib.call("d2s_copy_rows", lib.ptr(src), *rowmap, lib.ptr(dst), *dst_map, rows, D)
+    lib.call("d2s_copy_rows", lib.ptr(src), *rowmap, lib.ptr(dst), *dst_map, rows, D, int(accumulate))
     return dst
+
+
+def unfold_fwd(src, strides, B, C, H, W, k, s, p):
+    """strides = (sb, sc, sy, sx) of the source seen as [B, C, H, W]; -> [B, Ho*Wo, C*k*k]"""
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    out = torch.empty((B, Ho * Wo, C * k * k), dtype=torch.float32, device=src.device)
+    lib.call("d2s_unfold_fwd", lib.ptr(src), *strides, lib.ptr(out), B, C, H, W, k, s, p)
+    return out
+
+
+def unfold_bwd(g, dsrc, strides, B, C, H, W, k, s, p):
+    lib.call("d2s_unfold_bwd", lib.ptr(g), lib.ptr(dsrc), *strides, B, C, H, W, k, s, p)
+    return dsrc
+
+
+def performer_attn_fwd(kqv, w, B, T, eps=1e-8):
+    dev = kqv.device
+    M = B * T
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    y, kp, qp, A, ksum, D = f(M, 64), f(M, 32), f(M, 32), f(B, 64, 32), f(B, 32), f(M)
+    ws = workspace(lib.query("d2s_performer_workspace_bytes", B, T), dev)
+    lib.call("d2s_performer_attn_fwd", lib.ptr(kqv), lib.ptr(w), lib.ptr(y), lib.ptr(kp), lib.ptr(qp), lib.ptr(A), lib.ptr(ksum),
+             lib.ptr(D), B, T, float(eps), lib.ptr(ws), ws.numel())
+    return y, kp, qp, A, ksum, D
+
+
+def performer_attn_bwd(kqv, w, y, kp, qp, A, ksum, D, gy, skip, B, T, eps=1e-8):
+    dev = kqv.device
+    M = B * T
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    dkqv, dnum, dD, dqp, dkp, dA, dksum = f(M, 192), f(M, 64), f(M), f(M, 32), f(M, 32), f(B, 64, 32), f(B, 32)
+    ws = workspace(lib.query("d2s_performer_workspace_bytes", B, T), dev)
+    lib.call("d2s_performer_attn_bwd", lib.ptr(kqv), lib.ptr(w), lib.ptr(y), lib.ptr(kp), lib.ptr(qp), lib.ptr(A), lib.ptr(ksum),
+             lib.ptr(D), lib.ptr(gy), lib.ptr(skip), lib.ptr(dkqv), lib.ptr(dnum), lib.ptr(dD), lib.ptr(dqp), lib.ptr(dkp), lib.ptr(dA),
+             lib.ptr(dksum), B, T, float(eps), lib.ptr(ws), ws.numel())
+    return dkqv
 
 
 def attn_fwd(qkv, B, n, H, scale, want_cls=True):

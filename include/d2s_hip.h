@@ -82,7 +82,25 @@ int d2s_fill_cls(const float* cls, const float* pos, float* tokens, int B, int n
 int d2s_batch_sum(const float* g, float* out, int B, long count, long image_stride, int accumulate, d2s_stream_t stream);
 int d2s_copy_rows(const float* src, long rows_per_group, long group_stride, long row_stride, long offset, float* dst,
                   long d_rows_per_group, long d_group_stride, long d_row_stride, long d_offset, long rows, int D,
-                  d2s_stream_t stream);
+                  int accumulate, d2s_stream_t stream);
+
+/* ---- Tokens-to-Token front end (vit_models/t2t_vit.py:45-104, token_performer.py:31-54) ------------------------------
+ * soft split = nn.Unfold(k, s, p)(x).transpose(1, 2); the source is addressed by strides (sb, sc, sy, sx) so that an NCHW
+ * image and the re-structurised token tensor [B, H*W, C] (t2t_vit.py:90,97) are both read in place. */
+/* t2t_vit.py:160-162: out[b,0] = cls + pos[0]; out[b,1+t] = tok[b,t] + pos[1+t] */
+int d2s_assemble_tokens(const float* tok, const float* cls, const float* pos, float* out, int B, int T, int D, d2s_stream_t stream);
+int d2s_unfold_fwd(const float* src, long sb, long sc, long sy, long sx, float* out, int B, int C, int H, int W, int k, int s,
+                   int p, d2s_stream_t stream);
+int d2s_unfold_bwd(const float* g, float* dsrc, long sb, long sc, long sy, long sx, int B, int C, int H, int W, int k, int s,
+                   int p, d2s_stream_t stream);
+/* FAVOR+ linear attention of Token_performer.single_attn (token_performer.py:45-50), emb 64, m 32: kqv rows [k|q|v]. */
+size_t d2s_performer_workspace_bytes(int B, int T);
+int d2s_performer_attn_fwd(const float* kqv, const float* w, float* y, float* kp, float* qp, float* A, float* ksum, float* D,
+                           int B, int T, float eps, void* workspace, size_t workspace_bytes, d2s_stream_t stream);
+int d2s_performer_attn_bwd(const float* kqv, const float* w, const float* y, const float* kp, const float* qp, const float* A,
+                           const float* ksum, const float* D, const float* gy, const float* skip, float* dkqv, float* dnum,
+                           float* dD, float* dqp, float* dkp, float* dA, float* dksum, int B, int T, float eps, void* workspace,
+                           size_t workspace_bytes, d2s_stream_t stream);
 
 /* ---- perturbed top-k (vit_models/peturbed_topk.py:16-80), noise injected ------------------------------------------ */
 size_t d2s_perturbed_topk_workspace_bytes(int b, int k, int d);
