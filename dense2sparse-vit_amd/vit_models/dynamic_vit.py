@@ -146,11 +146,16 @@ class PredictorLG(nn.Module):
         super().__init__()
         if use_bn:
             raise NotImplementedError("--predictor-bn is not on the accelerated hot path (SURVEY 8f.4)")
-        if small_predictor:
-            raise NotImplementedError("--small-predictor is not on the accelerated hot path yet (SURVEY 8f.4)")
         self.small_predictor, self.k, self.topk_selection, self.loss_type = small_predictor, k, topk_selection, loss_type
         D = embed_dim
         relu = nn.ReLU()
+        if small_predictor:      # :409-426 (LayerNorm + GELU variant)
+            self.in_conv = nn.Sequential(nn.LayerNorm(D), nn.Linear(D, D), nn.GELU())
+            self.out_conv = nn.Sequential(nn.LayerNorm(D), nn.Linear(D, D // 2), nn.GELU(), nn.LayerNorm(D // 2),
+                                          nn.Linear(D // 2, D // 4), nn.GELU(), nn.LayerNorm(D // 4), nn.Linear(D // 4, 1),
+                                          nn.Flatten(start_dim=-2, end_dim=-1))
+            self.topk = PerturbedTopK(k)
+            return
         self.in_conv = nn.Sequential(nn.LayerNorm(D), nn.Linear(D, D * 4), relu)
         self.out_conv = nn.Sequential(
             nn.LayerNorm(D * 4), nn.Linear(D * 4, D * 2), relu,
@@ -162,7 +167,7 @@ class PredictorLG(nn.Module):
 
     def _params(self):
         ps = [self.in_conv[0].weight, self.in_conv[0].bias, self.in_conv[1].weight, self.in_conv[1].bias]
-        for i in (0, 3, 6, 9, 12):
+        for i in ((0, 3, 6) if self.small_predictor else (0, 3, 6, 9, 12)):
             ps += [self.out_conv[i].weight, self.out_conv[i].bias, self.out_conv[i + 1].weight, self.out_conv[i + 1].bias]
         return ps
 
@@ -172,6 +177,9 @@ class PredictorLG(nn.Module):
             return None  # the reference's forward falls through and returns None (:537)
         if self.loss_type not in ("kl_div", "mse"):
             raise NotImplementedError("sigmoid scores (bce loss type) are not on the accelerated hot path")
+        if self.small_predictor:
+            from d2s.functional_small import SmallPredictorFn
+            return SmallPredictorFn.apply(x_with_cls, *self._params())
         return DF.PredictorFn.apply(x_with_cls, *self._params())
 
     def forward(self, x, policy=None, current_sigma=0.0005, cls_attn=None):

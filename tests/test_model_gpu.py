@@ -19,7 +19,7 @@ from tests import cases
 from oracle import d2s_oracle as O
 
 pytestmark = pytest.mark.gpu
-HIP_CASES = [n for n in cases.MODEL_CASES if not cases.MODEL_CASES[n]["cfg"]["small_predictor"]]
+HIP_CASES = list(cases.MODEL_CASES)
 
 
 def _t(a):
@@ -32,7 +32,8 @@ def build_models(case, device):
     common = dict(img_size=cfg["img_size"], patch_size=cfg["patch"], embed_dim=cfg["dim"], depth=cfg["depth"],
                   num_heads=cfg["heads"], mlp_ratio=cfg["mlp_ratio"], qkv_bias=True, num_classes=cfg["num_classes"])
     student = vit_models.VisionTransformerDiffPruning(pruning_loc=list(cfg["pruning_loc"]), token_ratio=list(cfg["token_ratio"]),
-                                                      distill=True, topk_selection=True, predictor_loss_type=cfg["loss_type"], **common)
+                                                      distill=True, topk_selection=True, predictor_loss_type=cfg["loss_type"],
+                                                      small_predictor=cfg["small_predictor"], **common)
     teacher = vit_models.VisionTransformerTeacher(**common)
     sd_s, sd_t = cases.make_weights(case)
     student.load_state_dict({k: _t(v) for k, v in sd_s.items()}, strict=True)
