@@ -1,0 +1,60 @@
+"""GPU tier: the caller-level counterparts (train.py::train_one_epoch, evaluate.py::evaluate_performance, utils.py param
+groups) run end to end on the accelerated modules, both with the fused TrainStep and with a plain torch.optim.AdamW built the
+way the reference builds it (mask_predictor.py:213-230)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+from tests.test_model_gpu import build_models, make_args
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(cfg, dev):
+    a = make_args(cfg)
+    a.device, a.warmup_steps, a.weight_decay, a.lr, a.min_lr, a.epochs, a.is_sbatch = dev, 0, 0.05, 5e-4, 1e-5, 25, False
+    return a
+
+
+def test_train_one_epoch_fused_and_torch_optimizer_agree():
+    from d2s.engine import TrainStep
+    from train import train_one_epoch
+    import utils
+    dev = torch.device("cuda:0")
+    case = cases.MODEL_CASES["micro1"]
+    cfg = case["cfg"]
+    loader = lambda: utils.SyntheticLoader(3, 4, img_size=cfg["img_size"], num_classes=cfg["num_classes"], seed=5, device=dev)
+    s1, t1, _, _ = build_models(case, dev)
+    a1 = _args(cfg, dev)
+    step = TrainStep(s1, t1, a1, lr=a1.lr, min_lr=a1.min_lr, weight_decay=a1.weight_decay, epochs=a1.epochs, warmup_steps=0)
+    m1 = train_one_epoch(a1, s1, t1, loader(), step)
+    s2, t2, _, _ = build_models(case, dev)
+    a2 = _args(cfg, dev)
+    groups = utils.get_param_groups(s2, a2)
+    opt = torch.optim.AdamW([g for g in groups if g["params"]], lr=a2.lr, weight_decay=a2.weight_decay)
+    utils.adjust_learning_rate(opt.param_groups, a2, 0, s2)
+    for p in t2.parameters():
+        p.requires_grad_(False)
+    m2 = train_one_epoch(a2, s2, t2, loader(), opt)
+    assert set(m1) == set(m2) and "train_loss" in m1 and "train_mask_loss" in m1 and "train_backbone_loss" in m1
+    np.testing.assert_allclose(m1["train_loss"], m2["train_loss"], rtol=1e-4)
+    for (n, p), (_, q) in zip(s1.named_parameters(), s2.named_parameters()):
+        d = (p.detach() - q.detach()).abs().max().item()
+        assert d <= 2 * 3 * a1.lr * 1.01, (n, d)          # Adam: noise-level gradients may move a few elements by lr per step
+
+
+def test_evaluate_performance_runs_and_reports():
+    from evaluate import evaluate_performance
+    import utils
+    dev = torch.device("cuda:0")
+    case = cases.MODEL_CASES["micro2"]
+    cfg = case["cfg"]
+    s, t, _, _ = build_models(case, dev)
+    a = _args(cfg, dev)
+    m = evaluate_performance(a, s, t, utils.SyntheticLoader(2, 4, img_size=cfg["img_size"], num_classes=cfg["num_classes"], seed=3, device=dev))
+    for k in ("val_loss", "val_acc", "unpruned_acc", "val_mask_loss", "val_mask_acc_0", "val_mask_acc_1"):
+        assert k in m, k
+    assert 0.0 <= m["val_acc"] <= 1.0 and m["val_acc"] == m["unpruned_acc"] and np.isfinite(m["val_loss"])
