@@ -358,6 +358,30 @@ class AddClsPosFn(torch.autograd.Function):
         return dtok, dcls, dpos
 
 
+class PolicySoftmaxFn(torch.autograd.Function):
+    """Attention.softmax_with_policy (dynamic_vit.py:195-214): attn [B,H,N,N], policy [B,N,1] or [B,N] -> probabilities."""
+
+    @staticmethod
+    def forward(ctx, attn, policy, eps):
+        B, H, N, _ = attn.shape
+        attn = attn.contiguous()
+        pol = policy.reshape(B, N).contiguous().float()
+        out = torch.empty_like(attn)
+        ops.lib.call("d2s_softmax_policy_fwd", ops.lib.ptr(attn), ops.lib.ptr(pol), ops.lib.ptr(out), B, H, N, float(eps))
+        ctx.save_for_backward(attn, pol)
+        ctx.eps = float(eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        attn, pol = ctx.saved_tensors
+        B, H, N, _ = attn.shape
+        ga = torch.empty_like(attn)
+        ops.lib.call("d2s_softmax_policy_bwd", ops.lib.ptr(attn), ops.lib.ptr(pol), ops.lib.ptr(g.contiguous()), ops.lib.ptr(ga), B, H, N,
+                     ctx.eps)
+        return ga, None, None
+
+
 def select_topk(keep_probs, k):
     """Hard top-k of the keep probabilities (dynamic_vit.py:858-862): (kept, dropped) int64, each ascending."""
     return ops.select_topk(keep_probs.detach().contiguous(), k)

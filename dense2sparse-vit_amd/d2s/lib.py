@@ -33,6 +33,8 @@ _SIGS = {
     "d2s_batch_sum": (I, [P, P, I, L, L, I]),
     "d2s_copy_rows": (I, [P, L, L, L, L, P, L, L, L, L, L, I, I]),
     "d2s_assemble_tokens": (I, [P, P, P, P, I, I, I]),
+    "d2s_softmax_policy_fwd": (I, [P, P, P, I, I, I, F]),
+    "d2s_softmax_policy_bwd": (I, [P, P, P, P, I, I, I, F]),
     "d2s_unfold_fwd": (I, [P, L, L, L, L, P, I, I, I, I, I, I, I]),
     "d2s_unfold_bwd": (I, [P, P, L, L, L, L, I, I, I, I, I, I, I]),
     "d2s_performer_workspace_bytes": (Z, [I, I]),

@@ -69,9 +69,14 @@ class Attention(nn.Module):
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim)
 
+    def softmax_with_policy(self, attn, policy, eps=1e-6):
+        """:195-214 on a materialised score tensor (the fused attention kernels do not take a policy yet)."""
+        return DF.PolicySoftmaxFn.apply(attn, policy, eps)
+
     def forward(self, x, policy=None, return_cls_attn=False):
         if policy is not None:
-            raise NotImplementedError("softmax_with_policy (patch_score_threshold path) is not on the accelerated hot path")
+            raise NotImplementedError("policy-masked fused attention (patch_score_threshold training path) is not built: the "
+                                      "reference path that needs it is broken end to end (dynamic_vit.py:936, losses.py:216-218)")
         B, N, C = x.shape
         qkv = DF.LinearFn.apply(x.reshape(B * N, C), self.qkv.weight, self.qkv.bias, None)
         o, cls_row = DF.AttnCoreFn.apply(qkv, B, N, self.num_heads, self.scale, bool(return_cls_attn))

@@ -65,6 +65,12 @@ int d2s_attn_fwd_f32(const float* qkv, float* out, float* lse, float* cls_row, i
 int d2s_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws,
                      int B, int n, int H, float scale, d2s_stream_t stream);
 
+/* Attention.softmax_with_policy (vit_models/dynamic_vit.py:195-214) on materialised scores [B,H,N,N], policy [B,N];
+ * the backward includes the path through the row maximum (the reference does not detach it). */
+int d2s_softmax_policy_fwd(const float* attn, const float* policy, float* out, int B, int H, int N, float eps, d2s_stream_t stream);
+int d2s_softmax_policy_bwd(const float* attn, const float* policy, const float* grad_out, float* grad_attn, int B, int H, int N,
+                           float eps, d2s_stream_t stream);
+
 /* ---- token scoring tail, selection, gather / scatter ------------------------------------------------------------- */
 /* F.softmax(scores, dim=-1), vit_models/dynamic_vit.py:551 */
 int d2s_softmax_rows(const float* scores, float* probs, int rows, int T, d2s_stream_t stream);

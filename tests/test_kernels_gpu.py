@@ -229,3 +229,36 @@ def test_attention_fwd_bwd(ops, B, n, H):
     np.testing.assert_allclose(cls_row.cpu().numpy(), cls_ref.detach().numpy(), rtol=1e-4, atol=1e-7)
     dqkv = ops.attn_bwd(qd, out, do.reshape(B * n, -1).to(_dev()), lse, B, n, H, 0.125)
     np.testing.assert_allclose(dqkv.cpu().numpy(), qr.grad.numpy(), rtol=2e-4, atol=5e-5)
+
+
+def test_softmax_with_policy_fwd_matches_reference_and_bwd_matches_autograd():
+    """Row 7 of SURVEY 8a: forward against the output of the reference's own Attention.softmax_with_policy (golden), backward
+    against autograd through the oracle restatement (which includes the path through the row maximum)."""
+    import vit_models
+    g = cases.load_golden("intermediates_micro1")
+    attn, pol = torch.from_numpy(g["policy_attn_in"]), torch.from_numpy(g["policy_mask"])
+    m = vit_models.Attention(128, num_heads=2, qkv_bias=True)
+    ad = attn.to(_dev()).requires_grad_(True)
+    out = m.softmax_with_policy(ad, pol.to(_dev()))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["policy_softmax"], rtol=2e-6, atol=1e-9)
+    ar = attn.clone().requires_grad_(True)
+    ref = O.softmax_with_policy(ar, pol)
+    go = _rand("psg", tuple(ref.shape))
+    ref.backward(go)
+    out.backward(go.to(_dev()))
+    np.testing.assert_allclose(ad.grad.cpu().numpy(), ar.grad.numpy(), rtol=1e-4, atol=1e-6)
+    # larger, with fully-kept and mostly-dropped rows
+    B, H, N = 2, 3, 197
+    attn = _rand("psa", (B, H, N, N), 2.0)
+    pol = (torch.rand(B, N, 1, generator=torch.Generator().manual_seed(1)) > 0.6).float()
+    pol[:, 0] = 1.0
+    pol[1] = 1.0
+    ar = attn.clone().requires_grad_(True)
+    ref = O.softmax_with_policy(ar, pol)
+    go = _rand("psg2", tuple(ref.shape))
+    ref.backward(go)
+    ad = attn.to(_dev()).requires_grad_(True)
+    out = m.softmax_with_policy(ad, pol.to(_dev()))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-9)
+    out.backward(go.to(_dev()))
+    np.testing.assert_allclose(ad.grad.cpu().numpy(), ar.grad.numpy(), rtol=2e-4, atol=1e-6)
