@@ -80,7 +80,30 @@ class KernelTimer:
             timer.records.setdefault(("gather_pack", ""), []).append((s, e, B * (2.0 * (k + 1) * D * 4 + 8.0 * k)))
             return out
 
-        ops.gemm, ops.gather_pack = gemm, gather_pack
+        orig_scatter = ops.scatter_unpack
+
+        def scatter_unpack(g, ids, n):
+            if not timer.enabled:
+                return orig_scatter(g, ids, n)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = orig_scatter(g, ids, n)
+            e.record()
+            B, k1, D = g.shape
+            timer.records.setdefault(("scatter_unpack", ""), []).append((s, e, B * (k1 * D * 4.0 + n * D * 4.0 + 8.0 * (k1 - 1))))
+            return out
+
+        ops.gemm, ops.gather_pack, ops.scatter_unpack = gemm, gather_pack, scatter_unpack
+        from d2s import lib as _lib
+        orig_call = _lib.call
+
+        def counted_call(name, *a):
+            if timer.enabled:
+                timer.launch_calls += 1
+            return orig_call(name, *a)
+
+        _lib.call = counted_call
+        self.launch_calls = 0
 
     def summary(self):
         out = {}
@@ -127,6 +150,33 @@ def cpu_baseline(keep, batch=32, warm=2, steps=10):
                 sample=f"{steps} full train steps of the CPU oracle at batch {batch} (same model/config, fp32), after {warm} warm-up; {dt:.1f} s")
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, KB -> bytes), or None."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_c_pmc_traffic.json")) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def gather_large(device, B=2048, n=197, k=98, D=384, iters=20):
+    """The gather at a size where launch latency no longer dominates: 624 MB of algorithmic traffic per launch."""
+    from d2s import ops
+    x = torch.randn((B, n, D), device=device)
+    ids = torch.sort(torch.rand((B, n - 1), device=device).argsort(dim=1)[:, :k], dim=1)[0].contiguous()
+    for _ in range(3):
+        ops.gather_pack(x, ids)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        ops.gather_pack(x, ids)
+    e.record()
+    torch.cuda.synchronize()
+    nbytes = B * (2.0 * (k + 1) * D * 4 + 8.0 * k)
+    gbs = nbytes / (s.elapsed_time(e) * 1e-3 / iters) / 1e9
+    return {"achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "bytes_per_launch": nbytes}
+
+
 def log(msg):
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
@@ -136,16 +186,23 @@ _T0 = time.perf_counter()
 
 def main():
     args = parse()
+    # RCCL prints a version banner on STDOUT at communicator creation; the contract is ONE JSON line there, so everything
+    # before the final print is routed to stderr at the file-descriptor level.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    force_dist = os.environ.get("D2S_FORCE_DIST") == "1"     # rehearse the RCCL path with a single rank
+    distributed = world > 1 or force_dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the d2s path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from d2s import ops, lib
@@ -159,6 +216,7 @@ def main():
     ts = TrainStep(student, teacher, targs, lr=5e-4, min_lr=1e-5, weight_decay=0.05, epochs=25, warmup_steps=0,
                    distributed=distributed)
     if distributed:
+        ts.reducer.force = force_dist
         dist.broadcast(ts.arena.params, src=0)
 
     g = torch.Generator(device=device).manual_seed(1234 + rank)
@@ -213,23 +271,35 @@ def main():
             ach = gemms[dom]["work"] / (gemms[dom]["ms"] * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "kernel": f"gemm_f32_kernel<{dom[1]}> (v_mfma_f32_32x32x2_f32)",
                                 "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("gemm_f32_kernel<0, 0, 128, 128>") if dom[1] == "NT" else None,
+                                "traffic_note": "HBM bytes per launch of the 128x128 NT variant from the committed PMC passes (profiles/r01_c_pmc_traffic.json); not collected live",
                                 "avg_launch_us": round(1000.0 * gemms[dom]["ms"] / gemms[dom]["launches"], 2),
                                 "launches_per_step": gemms[dom]["launches"] / args.steps,
                                 "all_gemm_layouts": {k[1]: {"TFLOP/s": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),
                                                             "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in gemms.items()},
                                 "gemm_share_of_step": round(tot_ms / (1000.0 * elapsed), 4),
                                 "gemm_family_TFLOP/s": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2)}
+        line["c_abi_calls_per_step"] = round(timer.launch_calls / args.steps, 1)
+        sc = summ.get(("scatter_unpack", ""))
+        if sc:
+            gbs = sc["work"] / (sc["ms"] * 1e-3) / 1e9
+            line["scatter"] = {"bound": "hbm", "kernel": "scatter_unpack_kernel", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": round(gbs / PEAK_HBM_GBS, 4), "bytes_per_launch": sc["work"] / sc["launches"],
+                               "avg_launch_us": round(1000.0 * sc["ms"] / sc["launches"], 2), "traffic": pmc_traffic("scatter_unpack_kernel")}
         ga = summ.get(("gather_pack", ""))
         if ga:
             gbs = ga["work"] / (ga["ms"] * 1e-3) / 1e9
             line["gather"] = {"bound": "hbm", "kernel": "gather_pack_kernel", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                               "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                              "bytes_per_launch": ga["work"] / ga["launches"], "avg_launch_us": round(1000.0 * ga["ms"] / ga["launches"], 2)}
+                              "bytes_per_launch": ga["work"] / ga["launches"], "avg_launch_us": round(1000.0 * ga["ms"] / ga["launches"], 2),
+                              "traffic": pmc_traffic("gather_pack_kernel"), "at_batch_2048": gather_large(device)}
         if n_gpus == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle (bounded sample)")
             line["cpu_baseline"] = cpu_baseline(args.keep)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if distributed:
         dist.destroy_process_group()
 

@@ -12,7 +12,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         name = r.get("Kernel_Name", "")
         if filters and not any(x in name for x in filters):
             continue
-        short = name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:70]
+        short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
         key = (short, r["Counter_Name"])
         acc[key][0] += float(r["Counter_Value"])
         acc[key][1] += 1
