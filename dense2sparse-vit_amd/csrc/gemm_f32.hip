@@ -15,6 +15,8 @@
 // transposing ds_write_b32 of k-contiguous operands and the ds_read_b32 fragment reads conflict-free.
 // Global->register prefetch of tile t+1 is issued before the 32 MFMAs of tile t; one barrier per K-step.
 #include "d2s_common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -44,6 +46,7 @@ struct GemmArgs {
     int vecA, vecB;    // 16-byte vector loads allowed for A / B
     // output row remap (patch embed writes token t of image b to row b*(T+1)+1+t): out_row = m + m / rows_per_img * skip + skip0
     int remap_rows_per_img; int remap_skip;
+    int stagger;       // de-synchronise the first residency round (speed only)
 };
 
 template <int LAY, int BR>
@@ -169,6 +172,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     const int kbeg = blockIdx.z * p.k_per_slice;
     const int kend = min(p.K, kbeg + p.k_per_slice);
     const int nk = (kend - kbeg + BK - 1) / BK;
+
+    // De-synchronise the first residency round.  All workgroups of a launch do identical work, so the RES workgroups that
+    // share a CU start together, share its matrix pipes evenly and would reach their prologue / epilogue (which cannot
+    // overlap their own MFMAs) at the same moment, every round.  Workgroup b and b + 256 tend to share a CU, so slot
+    // j = (b / 256) % RES is delayed once by j x (the MFMA time of one tile running alone); after that the slots stay out
+    // of phase and one workgroup's gaps hide under the others' matrix work.  Only timing depends on it.
+    if (p.stagger) {
+        constexpr int RES = (BM == 128 && BN == 128) ? 3 : (BM == 64 && BN == 64) ? 8 : 5;
+        const int lin = blockIdx.z * gridDim.x + blockIdx.x;
+        if (lin < 256 * RES) {
+            const int j = (lin >> 8) % RES;
+            const long wait_cycles = (long)j * nk * (BK / 2) * MT * NT * 64;
+            const long t0 = (long)__builtin_amdgcn_s_memtime();
+            while ((long)__builtin_amdgcn_s_memtime() - t0 < wait_cycles) __builtin_amdgcn_s_sleep(32);
+        }
+    }
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -329,6 +348,10 @@ int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb,
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
     p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.aux_rows = aux_rows > 0 ? aux_rows : 1;
     p.remap_rows_per_img = remap_rows_per_img; p.remap_skip = remap_skip;
+    {
+        static const int stagger_env = [] { const char* e = getenv("D2S_GEMM_STAGGER"); return e ? atoi(e) : 0; }();   // experiment knob; measured: no gain
+        p.stagger = stagger_env;
+    }
     const int alay = layout == 2 ? 1 : 0, blay = layout == 0 ? 0 : 1;
     p.vecA = aligned16(A) && (lda % 4 == 0) && (alay == 0 ? (K % 4 == 0) : (M % 4 == 0));
     p.vecB = aligned16(B) && (ldb % 4 == 0) && (blay == 0 ? (K % 4 == 0) : (N % 4 == 0));

@@ -37,6 +37,10 @@ MODEL_CASES = {
                       batch=2, seed=32),
     "small_3stage": dict(cfg=O.make_cfg(dim=384, depth=12, heads=6, pruning_loc=(3, 6, 9),
                                         token_ratio=(0.7, 0.5, 0.3)), batch=2, seed=33),
+    # BASELINE config 5 geometry: DeiT-Base 384x384 (577 tokens), keep 0.3 with the reference's hard-coded init_n = 196,
+    # i.e. int(196 * 0.3) = 58 of 576 tokens survive (dynamic_vit.py:828,852)
+    "base384_k30": dict(cfg=O.make_cfg(img_size=384, dim=768, depth=12, heads=12, pruning_loc=(3,), token_ratio=(0.3,)),
+                        batch=1, seed=51),
 }
 
 # tag -> (b, nS, d, k, sigma)
