@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--keep", type=float, default=0.5)
+    ap.add_argument("--gemm-mode", choices=["exact", "split", "bf16"], default="exact",
+                    help="exact: v_mfma_f32_32x32x2_f32 (default, fp32 fma chain); split: bf16x3 on the bf16 matrix cores, fp32-class "
+                         "accuracy; bf16: bf16 operands, fp32 accumulate (forward/dgrad GEMMs; wgrad stays exact)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events (pure step timing)")
     return ap.parse_args()
@@ -208,6 +211,7 @@ def main():
     from d2s import ops, lib
     from d2s.engine import TrainStep
     lib.load()
+    ops.set_gemm_mode({"exact": 0, "split": 1, "bf16": 2}[args.gemm_mode])
     timer = KernelTimer()
     timer.wrap(ops)
 
@@ -257,7 +261,7 @@ def main():
             "metric": "training images/s, DeiT-S 224 keep_ratio=0.5 (dense-to-sparse ViT train step, teacher fwd + student fwd/bwd + AdamW)",
             "value": round(imgs / elapsed, 2), "unit": "images/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (N(0,1) images, uniform labels, random-init weights)",
+            "vs_baseline": None, "dtype": {"exact": "f32", "split": "f32 (bf16x3-split MFMA, fp32-class accuracy)", "bf16": "bf16 GEMM operands, f32 accumulate/elsewhere"}[args.gemm_mode], "data": "synthetic (N(0,1) images, uniform labels, random-init weights)",
             "config": {"workload": f"DeiT-Small 224x224 patch16, 1-stage prune keep_ratio={args.keep} @ block 3 (196->{int(196 * args.keep)} tokens), "
                                    f"large LN predictor, kl_div mask loss, per-GPU batch {args.batch}",
                        "global_batch": args.batch * n_gpus, "parallelism": f"dp{n_gpus}", "final_loss": round(loss, 5)},

@@ -14,40 +14,14 @@
 // VGPRs).  LDS image is [k][row] with the row index XOR-swizzled by ((k>>2)&3)<<3, which makes both the
 // transposing ds_write_b32 of k-contiguous operands and the ds_read_b32 fragment reads conflict-free.
 // Global->register prefetch of tile t+1 is issued before the 32 MFMAs of tile t; one barrier per K-step.
-#include "d2s_common.h"
+#include "gemm_common.h"
 #include <cstdio>
 #include <cstdlib>
 
 namespace {
+using namespace d2s_gemm;
 
 constexpr int BK = 16;
-
-enum Epi : int {
-    EPI_NONE = 0,
-    EPI_BIAS = 1,          // C = acc + bias[n]
-    EPI_BIAS_RELU = 2,     // C = relu(acc + bias[n])
-    EPI_BIAS_GELU = 3,     // aux_out = acc + bias[n] (pre-activation, if given); C = gelu(.)
-    EPI_BIAS_RESID = 4,    // C = acc + bias[n] + aux[m][n]
-    EPI_MUL_GELU_GRAD = 5, // C = acc * gelu'(aux[m][n])      (aux = saved pre-activation)
-    EPI_MUL_RELU_MASK = 6, // C = acc * (aux[m][n] > 0)       (aux = saved ReLU output)
-    EPI_BIAS_ROWADD = 7,   // C = acc + bias[n] + aux[(m % aux_rows)][n]  (patch embed: + pos_embed rows)
-    EPI_ACCUM = 8,         // C += acc
-};
-
-struct GemmArgs {
-    const float* A; const float* B; float* C;
-    const float* bias; const float* aux; float* aux_out;
-    long lda, ldb, ldc, ldaux;
-    int M, N, K;
-    int epi;
-    int k_per_slice;   // reduction elements per blockIdx.z slice (multiple of BK)
-    long slab_stride;  // elements between split-K slabs (0 when gridDim.z == 1)
-    int aux_rows;      // EPI_BIAS_ROWADD
-    int vecA, vecB;    // 16-byte vector loads allowed for A / B
-    // output row remap (patch embed writes token t of image b to row b*(T+1)+1+t): out_row = m + m / rows_per_img * skip + skip0
-    int remap_rows_per_img; int remap_skip;
-    int stagger;       // de-synchronise the first residency round (speed only)
-};
 
 template <int LAY, int BR>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, int row0, int k0, int rows, int kend,
@@ -104,45 +78,6 @@ __device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const
             const int k = f / (BR / 4), row = (f % (BR / 4)) * 4;
             const int col = row ^ (((k >> 2) & 3) << 3);
             *reinterpret_cast<f32x4*>(&S[k * BR + col]) = r[i];
-        }
-    }
-}
-
-template <int EPI, int MT, int NT>
-__device__ __forceinline__ void store_tile_out(const GemmArgs& p, float* __restrict__ Cb, const f32x16 (&acc)[MT][NT], int mbase,
-                                               int nbase, int half) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = nbase + nt * 32;
-        if (n >= p.N) continue;
-        float bias = 0.f;
-        if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_ROWADD)
-            bias = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mbase + mt * 32 + mfma32_row(r, half);
-                if (m >= p.M) continue;
-                float v = acc[mt][nt][r];
-                long orow = m;
-                if (EPI == EPI_BIAS_ROWADD && p.remap_rows_per_img > 0)
-                    orow = (long)m + (long)(m / p.remap_rows_per_img) * p.remap_skip + p.remap_skip;
-                float* cp = Cb + orow * p.ldc + n;
-                if (EPI == EPI_BIAS) v += bias;
-                if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
-                if (EPI == EPI_BIAS_GELU) {
-                    v += bias;
-                    if (p.aux_out) p.aux_out[(long)m * p.ldc + n] = v;
-                    v = gelu_erf(v);
-                }
-                if (EPI == EPI_BIAS_RESID) v += bias + p.aux[(long)m * p.ldaux + n];
-                if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(p.aux[(long)m * p.ldaux + n]);
-                if (EPI == EPI_MUL_RELU_MASK) v = p.aux[(long)m * p.ldaux + n] > 0.f ? v : 0.f;
-                if (EPI == EPI_BIAS_ROWADD) v += bias + p.aux[(long)(m % p.aux_rows) * p.ldaux + n];
-                if (EPI == EPI_ACCUM) v += *cp;
-                *cp = v;
-            }
         }
     }
 }
@@ -289,7 +224,6 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     out[n] = accumulate ? out[n] + s : s;
 }
 
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Tile choice.  All workgroups of one launch cost the same, and a CU's matrix pipes are the bottleneck, so the launch
 // lasts ceil(nWG / 256 CUs) "rounds" of one tile's work: pick the tile that minimises rounds * tile area (small
@@ -320,10 +254,22 @@ inline void launch_gemm(const Tile& t, dim3 grid, hipStream_t stream, const Gemm
 
 }  // namespace
 
+namespace d2s_gemm {
+size_t split_workspace_bytes(int split, int M, int N, int K);
+int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace, size_t workspace_bytes, hipStream_t stream);
+}
+static int g_gemm_mode = 0;
+
 extern "C" {
 
 // Workspace needed by d2s_gemm_f32 for a given problem (only the TN / wgrad layout splits K).
+// 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  1: bf16x3 split on the bf16 matrix cores, fp32-class accuracy (gemm_split.hip).
+// 2: bf16 operands, fp32 accumulation.  Applies to the NT and NN layouts; wgrad (TN) always runs the exact kernel.
+void d2s_set_gemm_mode(int mode) { g_gemm_mode = (mode == 1 || mode == 2) ? mode : 0; }
+int d2s_get_gemm_mode(void) { return g_gemm_mode; }
+
 size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K) {
+    if (layout != 2 && g_gemm_mode != 0) return split_workspace_bytes(g_gemm_mode == 1 ? 3 : 1, M, N, K);   // bf16 piece matrices
     if (layout != 2) return 0;
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     int slices = (1024 + tiles - 1) / tiles;
@@ -355,6 +301,12 @@ int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb,
     const int alay = layout == 2 ? 1 : 0, blay = layout == 0 ? 0 : 1;
     p.vecA = aligned16(A) && (lda % 4 == 0) && (alay == 0 ? (K % 4 == 0) : (M % 4 == 0));
     p.vecB = aligned16(B) && (ldb % 4 == 0) && (blay == 0 ? (K % 4 == 0) : (N % 4 == 0));
+    if (g_gemm_mode != 0 && layout != 2) {
+        if (accumulate) p.epi = EPI_ACCUM;
+        p.k_per_slice = K;
+        p.slab_stride = 0;
+        return launch_split_gemm(p, layout == 1 ? 1 : 0, g_gemm_mode == 1 ? 3 : 1, workspace, workspace_bytes, stream);
+    }
     Tile tile = layout == 2 ? Tile{128, 128, 1.f} : pick_tile(M, N);
     const int tiles = ((M + tile.bm - 1) / tile.bm) * ((N + tile.bn - 1) / tile.bn);
     int slices = 1;

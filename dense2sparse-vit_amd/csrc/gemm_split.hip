@@ -1,0 +1,249 @@
+// fp32-ACCURATE GEMM on the bf16 matrix cores of gfx950 ("bf16x3 split"), and with one piece a plain bf16-compute GEMM.
+//
+// gfx950 multiplies fp32 matrices at 157 TFLOP/s (v_mfma_f32_32x32x2_f32) but bf16 matrices at ~2.5 PFLOP/s.  Every fp32
+// value is the exact sum of three bf16 numbers up to 2^-25 relative error: h = bf16(a), m = bf16(a - h), l = bf16(a - h - m)
+// (8 + 8 + 8 mantissa bits; the subtractions are exact in fp32).  bf16 x bf16 products are exact in the fp32 accumulator, so
+//     a*b = h_a h_b + (h_a m_b + m_a h_b) + (h_a l_b + l_a h_b + m_a m_b) + O(2^-24)
+// needs 6 bf16 MFMAs per 32x32x16 block for an error of ~2^-24 per product - the same class as fp32 rounding - at an
+// effective peak of 2.5 PF / 6 = 416 TFLOP/s, 2.65x the native fp32 matrix peak.  SPLIT = 1 keeps only h_a h_b: a bf16
+// GEMM with fp32 accumulation (BASELINE config 5's bf16 regime).  Inputs and outputs stay fp32; the C ABI is unchanged.
+//
+// Two stages inside one d2s_gemm_f32 call:
+//   1. split pass (HBM-bound, streaming): each operand is read once (fp32) and written as SPLIT bf16 "piece" matrices
+//      [SPLIT][rows][Kp] (Kp = K rounded up to 32, zero padded).  Doing it once per operand instead of once per output tile
+//      removes the 3-12x redundant conversion work of splitting inside the GEMM main loop.  For the dgrad layout (B stored
+//      [K][N]) the pass transposes through LDS, so the matrix kernel only ever sees K-contiguous pieces.
+//   2. matrix kernel: tile 128x128x32, 4 waves 2x2, each 64x64 = 2x2 tiles of v_mfma_f32_32x32x16_bf16; pieces are loaded with
+//      16-byte loads straight into an LDS image [piece][row][40 bf16] (80-byte pitch: conflict-free ds_read_b128 fragments),
+//      next K-slab prefetched to registers during the MFMAs, no VALU work in the loop; 2 workgroups per CU.
+#include "gemm_common.h"
+#include <cstdlib>
+
+namespace {
+using namespace d2s_gemm;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SBM = 128, SBN = 128;
+
+__device__ __forceinline__ void split3(float a, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)a;
+    const float r1 = a - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+// ---- stage 1a: row-major source [R][K] (ld) -> pieces [SPLIT][R][Kp] -------------------------------------------------------
+template <int SPLIT>
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, long ld, __bf16* __restrict__ dst, int R, int K,
+                                                         int Kp, int vec) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;     // one thread per 4 consecutive k of one row
+    const int kq = Kp >> 2;
+    if (e >= (long)R * kq) return;
+    const int row = (int)(e / kq), k = (int)(e - (long)row * kq) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const float* p = src + (long)row * ld + k;
+    if (vec && k + 3 < K) {
+        v = *reinterpret_cast<const f32x4*>(p);
+    } else {
+        if (k + 0 < K) v[0] = p[0];
+        if (k + 1 < K) v[1] = p[1];
+        if (k + 2 < K) v[2] = p[2];
+        if (k + 3 < K) v[3] = p[3];
+    }
+    bf16x4 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        __bf16 hh, mm = (__bf16)0.f, ll = (__bf16)0.f;
+        if constexpr (SPLIT == 3) split3(v[j], hh, mm, ll);
+        else hh = (__bf16)v[j];
+        h[j] = hh; m[j] = mm; l[j] = ll;
+    }
+    __bf16* d = dst + (long)row * Kp + k;
+    *reinterpret_cast<bf16x4*>(d) = h;
+    if constexpr (SPLIT == 3) {
+        *reinterpret_cast<bf16x4*>(d + (long)R * Kp) = m;
+        *reinterpret_cast<bf16x4*>(d + 2L * R * Kp) = l;
+    }
+}
+
+// ---- stage 1b: source [K][R] (ld, row index contiguous) -> pieces [SPLIT][R][Kp], 32x32 transposes through LDS ------------------
+template <int SPLIT>
+__global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict__ src, long ld, __bf16* __restrict__ dst, int R, int K,
+                                                         int Kp) {
+    __shared__ float t[32][33];
+    const int r0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)          // read: k = k0 + j, r = r0 + tx (coalesced along r)
+        t[j][tx] = (k0 + j < K && r0 + tx < R) ? src[(long)(k0 + j) * ld + r0 + tx] : 0.f;
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {        // write: r = r0 + j, k = k0 + tx (coalesced along k)
+        if (r0 + j >= R) continue;
+        const float a = t[tx][j];
+        __bf16 h, m = (__bf16)0.f, l = (__bf16)0.f;
+        if constexpr (SPLIT == 3) split3(a, h, m, l);
+        else h = (__bf16)a;
+        __bf16* d = dst + (long)(r0 + j) * Kp + k0 + tx;
+        *d = h;
+        if constexpr (SPLIT == 3) { d[(long)R * Kp] = m; d[2L * R * Kp] = l; }
+    }
+}
+
+// ---- stage 2: the matrix kernel on ready-made pieces ------------------------------------------------------------------------
+template <int SPLIT, int BK>
+__device__ __forceinline__ void load_pieces(const __bf16* __restrict__ P, int rows, int Kp, int row0, int k0, int tid,
+                                            u32x4 (&r)[SPLIT][BK / 16]) {
+    constexpr int CH = BK / 8;                                  // 16-byte chunks (8 bf16) per K-slab row
+#pragma unroll
+    for (int i = 0; i < BK / 16; ++i) {
+        const int f = tid + i * 256;
+        const int row = row0 + f / CH, ch = f % CH;
+#pragma unroll
+        for (int s = 0; s < SPLIT; ++s) {
+            if (row < rows) r[s][i] = *reinterpret_cast<const u32x4*>(P + ((long)s * rows + row) * Kp + k0 + ch * 8);
+            else r[s][i] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+}
+template <int SPLIT, int BK>
+__device__ __forceinline__ void store_pieces(__bf16* __restrict__ S, int tid, const u32x4 (&r)[SPLIT][BK / 16]) {
+    constexpr int CH = BK / 8, PITCH = BK + 8;
+#pragma unroll
+    for (int i = 0; i < BK / 16; ++i) {
+        const int f = tid + i * 256;
+        const int row = f / CH, ch = f % CH;
+#pragma unroll
+        for (int s = 0; s < SPLIT; ++s) *reinterpret_cast<u32x4*>(S + (s * 128 + row) * PITCH + ch * 8) = r[s][i];
+    }
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+struct PieceArgs { const __bf16* Ap; const __bf16* Bp; int Kp; };
+
+template <int SPLIT, int BK>
+__global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, PieceArgs q) {
+    constexpr int SBK = BK, PITCH = BK + 8;   // LDS row pitch in bf16: 80 B (BK 32) / 48 B (BK 16), both conflict-free for b128 reads
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* As = reinterpret_cast<__bf16*>(smem_raw);   // [SPLIT][128][PITCH]
+    __bf16* Bs = As + SPLIT * SBM * PITCH;               // [SPLIT][128][PITCH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nbm = (p.M + SBM - 1) / SBM, nbn = (p.N + SBN - 1) / SBN;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap (same as the f32 kernel): consecutive tiles of one A panel share an L2
+        const int qq = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+    }
+    const int row0 = (bid / nbn) * SBM, col0 = (bid % nbn) * SBN;
+    const int nk = q.Kp / SBK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 ra[SPLIT][BK / 16], rb[SPLIT][BK / 16];
+    load_pieces<SPLIT, BK>(q.Ap, p.M, q.Kp, row0, 0, tid, ra);
+    load_pieces<SPLIT, BK>(q.Bp, p.N, q.Kp, col0, 0, tid, rb);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        store_pieces<SPLIT, BK>(As, tid, ra);
+        store_pieces<SPLIT, BK>(Bs, tid, rb);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            load_pieces<SPLIT, BK>(q.Ap, p.M, q.Kp, row0, (kt + 1) * SBK, tid, ra);
+            load_pieces<SPLIT, BK>(q.Bp, p.N, q.Kp, col0, (kt + 1) * SBK, tid, rb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 a[SPLIT][2], b[SPLIT][2];
+#pragma unroll
+            for (int s = 0; s < SPLIT; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a[s][t] = *reinterpret_cast<const bf16x8*>(As + (s * SBM + wm * 64 + t * 32 + l31) * PITCH + ks * 16 + 8 * half);
+                    b[s][t] = *reinterpret_cast<const bf16x8*>(Bs + (s * SBN + wn * 64 + t * 32 + l31) * PITCH + ks * 16 + 8 * half);
+                }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    f32x16 c = acc[mt][nt];
+                    if constexpr (SPLIT == 3) {   // smallest terms first
+                        c = mfma_bf16(a[0][mt], b[2][nt], c);
+                        c = mfma_bf16(a[2][mt], b[0][nt], c);
+                        c = mfma_bf16(a[1][mt], b[1][nt], c);
+                        c = mfma_bf16(a[0][mt], b[1][nt], c);
+                        c = mfma_bf16(a[1][mt], b[0][nt], c);
+                    }
+                    acc[mt][nt] = mfma_bf16(a[0][mt], b[0][nt], c);
+                }
+        }
+        __syncthreads();
+    }
+
+    const int mbase = row0 + wm * 64, nbase = col0 + wn * 64 + l31;
+    switch (p.epi) {
+        case EPI_BIAS: store_tile_out<EPI_BIAS, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
+        case EPI_BIAS_RELU: store_tile_out<EPI_BIAS_RELU, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
+        case EPI_BIAS_GELU: store_tile_out<EPI_BIAS_GELU, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
+        case EPI_BIAS_RESID: store_tile_out<EPI_BIAS_RESID, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
+        case EPI_MUL_GELU_GRAD: store_tile_out<EPI_MUL_GELU_GRAD, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
+        case EPI_MUL_RELU_MASK: store_tile_out<EPI_MUL_RELU_MASK, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
+        case EPI_BIAS_ROWADD: store_tile_out<EPI_BIAS_ROWADD, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
+        case EPI_ACCUM: store_tile_out<EPI_ACCUM, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
+        default: store_tile_out<EPI_NONE, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
+    }
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+namespace d2s_gemm {
+
+size_t split_workspace_bytes(int split, int M, int N, int K) {
+    const size_t Kp = (size_t)((K + 31) / 32) * 32;
+    return align256((size_t)split * M * Kp * sizeof(__bf16)) + align256((size_t)split * N * Kp * sizeof(__bf16));
+}
+
+// C[M,N] = epi(A[M,K] * B^T) with B given as [N][K] (b_cols = 0) or as [K][N] (b_cols = 1, the dgrad layout).
+int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const int Kp = ((p.K + 31) / 32) * 32;
+    if (!workspace || workspace_bytes < split_workspace_bytes(split, p.M, p.N, p.K)) return D2S_ERR_WORKSPACE;
+    __bf16* Ap = static_cast<__bf16*>(workspace);
+    __bf16* Bp = reinterpret_cast<__bf16*>(static_cast<unsigned char*>(workspace) + align256((size_t)split * p.M * Kp * sizeof(__bf16)));
+    const long ea = (long)p.M * (Kp / 4), eb = (long)p.N * (Kp / 4);
+    dim3 block(256);
+    if (split == 3) {
+        hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)((ea + 255) / 256)), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
+        if (b_cols) hipLaunchKernelGGL(split_cols_kernel<3>, dim3((p.N + 31) / 32, Kp / 32), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp);
+        else hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)((eb + 255) / 256)), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
+    } else {
+        hipLaunchKernelGGL(split_rows_kernel<1>, dim3((unsigned)((ea + 255) / 256)), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
+        if (b_cols) hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.N + 31) / 32, Kp / 32), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp);
+        else hipLaunchKernelGGL(split_rows_kernel<1>, dim3((unsigned)((eb + 255) / 256)), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
+    }
+    const int tiles = ((p.M + SBM - 1) / SBM) * ((p.N + SBN - 1) / SBN);
+    static const int bk = [] { const char* e = getenv("D2S_SPLIT_BK"); return (e && atoi(e) == 32) ? 32 : 16; }();
+    const size_t lds = (size_t)split * (SBM + SBN) * (bk + 8) * sizeof(__bf16);
+    PieceArgs q{Ap, Bp, Kp};
+    if (split == 3 && bk == 32) hipLaunchKernelGGL((gemm_pieces_nt_kernel<3, 32>), dim3(tiles), block, lds, stream, p, q);
+    else if (split == 3) hipLaunchKernelGGL((gemm_pieces_nt_kernel<3, 16>), dim3(tiles), block, lds, stream, p, q);
+    else if (bk == 32) hipLaunchKernelGGL((gemm_pieces_nt_kernel<1, 32>), dim3(tiles), block, lds, stream, p, q);
+    else hipLaunchKernelGGL((gemm_pieces_nt_kernel<1, 16>), dim3(tiles), block, lds, stream, p, q);
+    return d2s_check_launch();
+}
+
+}  // namespace d2s_gemm

@@ -16,6 +16,8 @@ P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ct
 
 # name -> (restype, [argtypes]); the trailing hipStream_t is appended automatically for int-returning entries
 _SIGS = {
+    "d2s_set_gemm_mode": (None, [I]),
+    "d2s_get_gemm_mode": (I, None),
     "d2s_gemm_f32_workspace_bytes": (Z, [I, I, I, I]),
     "d2s_gemm_f32": (I, [I, P, L, P, L, P, L, I, I, I, I, P, P, L, P, I, I, I, I, P, Z]),
     "d2s_colsum_workspace_bytes": (Z, [I, I]),

@@ -262,3 +262,32 @@ def test_softmax_with_policy_fwd_matches_reference_and_bwd_matches_autograd():
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-9)
     out.backward(go.to(_dev()))
     np.testing.assert_allclose(ad.grad.cpu().numpy(), ar.grad.numpy(), rtol=2e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM arithmetic modes
+@pytest.mark.parametrize("mode,rtol,atol", [(1, 1e-4, 2e-5), (2, 3e-2, 3e-2)])
+def test_gemm_split_modes(ops, mode, rtol, atol):
+    """mode 1 (bf16x3 split on the bf16 matrix cores) must meet the SAME tolerance as the exact fp32 kernel and be as close to
+    an fp64 product as the CPU's fp32 GEMM is; mode 2 (plain bf16 operands) only the bf16 tolerance."""
+    from d2s import lib
+    lib.load().d2s_set_gemm_mode(mode)
+    try:
+        for (M, N, K) in ((197 * 2, 1152, 384), (300, 96, 192), (128, 1000, 384), (391, 200, 36), (50, 1, 96), (1024, 1536, 384), (77, 192, 147)):
+            x, w, b = _rand("mx", (M, K)), _rand("mw", (N, K), 0.05), _rand("mb", (N,), 0.1)
+            ref64 = F.linear(x.double(), w.double(), b.double())
+            ref32 = F.linear(x, w, b)
+            got = ops.linear_fwd(x.to(_dev()), w.to(_dev()), b.to(_dev())).cpu()
+            np.testing.assert_allclose(got.numpy(), ref32.numpy(), rtol=rtol, atol=atol)
+            if mode == 1:
+                e_hip = float((got.double() - ref64).norm() / ref64.norm())
+                e_cpu = float((ref32.double() - ref64).norm() / ref64.norm())
+                assert e_hip <= max(4 * e_cpu, 3e-7), (M, N, K, e_hip, e_cpu)
+            # dgrad goes through the transposed-weight NT path
+            dy = _rand("mdy", (M, N))
+            dx = ops.linear_dgrad(dy.to(_dev()), w.to(_dev())).cpu()
+            np.testing.assert_allclose(dx.numpy(), (dy @ w).numpy(), rtol=rtol, atol=atol * 10)
+            r = _rand("mr", (M, N))
+            got = ops.linear_fwd(x.to(_dev()), w.to(_dev()), b.to(_dev()), epi=ops.EPI_BIAS_RESID, aux=r.to(_dev())).cpu()
+            np.testing.assert_allclose(got.numpy(), (ref32 + r).numpy(), rtol=rtol, atol=atol)
+    finally:
+        lib.load().d2s_set_gemm_mode(0)

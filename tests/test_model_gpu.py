@@ -237,3 +237,36 @@ def test_full_size_properties_deit_small_batch128():
     back = ops.scatter_unpack(packed, kept[0], 197)
     np.testing.assert_array_equal(ops.gather_pack(back, kept[0]).cpu().numpy(), packed.cpu().numpy())
     assert torch.isfinite(logits).all()
+
+
+@pytest.mark.parametrize("name", ["micro2", "small_k50"])
+def test_split_gemm_mode_keeps_fp32_parity(name):
+    """GEMM mode 1 (bf16x3 split on the bf16 matrix cores): same assertions as the exact mode - kept ids bit-exact against the
+    reference fixture, logits / losses at the fp32 tolerances."""
+    from d2s.engine import TrainStep
+    from d2s import ops
+    dev = torch.device("cuda:0")
+    case = cases.MODEL_CASES[name]
+    cfg = case["cfg"]
+    g = cases.load_golden("model_" + name)
+    ops.set_gemm_mode(ops.GEMM_SPLIT)
+    try:
+        student, teacher, sd_s, sd_t = build_models(case, dev)
+        x, y = _t(cases.make_images(case)), _t(cases.make_labels(case))
+        ts = TrainStep(student, teacher, make_args(cfg), warmup_steps=0)
+        student.train()
+        loss, info = ts.forward_losses(x.to(dev), y.to(dev))
+        ts.opt.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_gemm_mode(ops.GEMM_EXACT)
+    for i, k in enumerate(info["kept"]):
+        np.testing.assert_array_equal(k.cpu().numpy(), g[f"kept_{i}"])
+    np.testing.assert_allclose(info["logits_s"].detach().cpu().numpy(), g["logits_s"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(info["logits_t"].cpu().numpy(), g["logits_t"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(float(info["mask_loss"]), float(g["mask_loss"]), rtol=2e-5)
+    np.testing.assert_allclose(float(info["backbone_loss"]), float(g["backbone_loss"]), rtol=2e-5)
+    params = dict(student.named_parameters())
+    for n, ref_norm in zip([str(s) for s in g["grad_names"]], g["grad_norms"]):
+        np.testing.assert_allclose(float(params[n].grad.double().norm()), ref_norm, rtol=1e-3, atol=1e-6, err_msg=n)
