@@ -30,6 +30,7 @@ struct GemmArgs {
     // output row remap (patch embed writes token t of image b to row b*(T+1)+1+t): out_row = m + m / rows_per_img * skip + skip0
     int remap_rows_per_img; int remap_skip;
     int stagger;       // de-synchronise the first residency round (speed only)
+    int vec_epilogue;  // 16-byte LDS-staged epilogue allowed (see epilogue_vec_ok)
 };
 
 template <int EPI, int MT, int NT>
@@ -71,6 +72,108 @@ __device__ __forceinline__ void store_tile_out(const GemmArgs& p, float* __restr
     }
 }
 
+// Same epilogue, but each wave first parks 16 rows of its accumulator sub-tile in a wave-private LDS buffer [16][WN + 4] and
+// reads them back row-wise, so that global traffic is 16-byte and row-contiguous (WN x 4 B per row) for the output AND for the
+// residual / activation-gradient operand: 4x fewer memory instructions than the dword form.  (The per-workgroup store tail was
+// measured at 8-12 us with dword stores - latency bound, not bandwidth bound - and about half that in this form.)  Requires
+// N % 4 == 0, ldc % 4 == 0 and 16-byte aligned bases; `stage_wave` points at epi_stage_floats(NT) floats of LDS per wave that
+// the main loop no longer uses (callers barrier after their last LDS read).
+__host__ __device__ constexpr int epi_stage_floats(int NT) { return 16 * (NT * 32 + 4); }
+
+template <int EPI, int MT, int NT>
+__device__ __forceinline__ void store_tile_out_lds(const GemmArgs& p, float* __restrict__ Cb, const f32x16 (&acc)[MT][NT], int mrow0,
+                                                   int ncol0, int lane, float* __restrict__ stage_wave) {
+    constexpr int WN = NT * 32, PITCH = WN + 4, LPR = WN / 4, RPI = 64 / LPR, ITERS = 16 / RPI;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int rr = lane / LPR, c4 = (lane % LPR) * 4;
+    const int n = ncol0 + c4;
+    constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_ROWADD;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (HAS_BIAS && p.bias && n < p.N) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8)
+                    stage_wave[((r8 & 3) + 8 * (r8 >> 2) + 4 * half) * PITCH + nt * 32 + l31] = acc[mt][nt][h2 * 8 + r8];
+            // same-wave LDS accesses complete in order: no barrier needed for the wave-private buffer
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int row = it * RPI + rr;
+                const int m = mrow0 + mt * 32 + h2 * 16 + row;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage_wave + row * PITCH + c4);
+                if (m >= p.M || n >= p.N) continue;
+                long orow = m;
+                if (EPI == EPI_BIAS_ROWADD && p.remap_rows_per_img > 0)
+                    orow = (long)m + (long)(m / p.remap_rows_per_img) * p.remap_skip + p.remap_skip;
+                float* cp = Cb + orow * p.ldc + n;
+                if (HAS_BIAS) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += bias[j];
+                }
+                if (EPI == EPI_BIAS_RELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                if (EPI == EPI_BIAS_GELU) {
+                    if (p.aux_out) *reinterpret_cast<f32x4*>(p.aux_out + (long)m * p.ldc + n) = v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+                }
+                if (EPI == EPI_BIAS_RESID || EPI == EPI_MUL_GELU_GRAD || EPI == EPI_MUL_RELU_MASK) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + (long)m * p.ldaux + n);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (EPI == EPI_BIAS_RESID) v[j] += a[j];
+                        if (EPI == EPI_MUL_GELU_GRAD) v[j] *= gelu_erf_grad(a[j]);
+                        if (EPI == EPI_MUL_RELU_MASK) v[j] = a[j] > 0.f ? v[j] : 0.f;
+                    }
+                }
+                if (EPI == EPI_BIAS_ROWADD) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + (long)(m % p.aux_rows) * p.ldaux + n);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += a[j];
+                }
+                if (EPI == EPI_ACCUM) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += o[j];
+                }
+                *reinterpret_cast<f32x4*>(cp) = v;
+            }
+        }
+    }
+}
+
+// resolve the (wave-uniform) epilogue kind once; each kind has its own straight-line store loop
+template <int MT, int NT>
+__device__ __forceinline__ void store_tile_dispatch_lds(int epi, const GemmArgs& p, float* Cb, const f32x16 (&acc)[MT][NT], int mr, int nc,
+                                                        int lane, float* stage) {
+    switch (epi) {
+        case EPI_BIAS: store_tile_out_lds<EPI_BIAS, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_BIAS_RELU: store_tile_out_lds<EPI_BIAS_RELU, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_BIAS_GELU: store_tile_out_lds<EPI_BIAS_GELU, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_BIAS_RESID: store_tile_out_lds<EPI_BIAS_RESID, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_MUL_GELU_GRAD: store_tile_out_lds<EPI_MUL_GELU_GRAD, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_MUL_RELU_MASK: store_tile_out_lds<EPI_MUL_RELU_MASK, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_BIAS_ROWADD: store_tile_out_lds<EPI_BIAS_ROWADD, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_ACCUM: store_tile_out_lds<EPI_ACCUM, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        default: store_tile_out_lds<EPI_NONE, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+    }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// can the 16-byte epilogue be used for this problem?
+inline bool epilogue_vec_ok(const GemmArgs& p) {
+    bool ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && aligned16(p.C);
+    if (p.bias) ok = ok && aligned16(p.bias);
+    if (p.aux) ok = ok && (p.ldaux % 4 == 0) && aligned16(p.aux);
+    if (p.aux_out) ok = ok && aligned16(p.aux_out);
+    return ok;
+}
 
 }  // namespace d2s_gemm

@@ -173,6 +173,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     // ---- epilogue: the (wave-uniform) epilogue kind is resolved ONCE, each kind has its own straight-line store loop ----
     float* Cb = p.C + (long)blockIdx.z * p.slab_stride;
     const int epi = (gridDim.z > 1) ? (int)EPI_NONE : p.epi;
+    static_assert(4 * epi_stage_floats(NT) <= 2 * BK * (BM + BN), "epilogue staging must fit the operand buffers");
+    if (p.vec_epilogue) {   // operand LDS is free after the loop's final barrier
+        store_tile_dispatch_lds<MT, NT>(epi, p, Cb, acc, row0 + wm * WM, col0 + wn * WN, lane, smem + wave * epi_stage_floats(NT));
+        return;
+    }
     const int mbase = row0 + wm * WM, nbase = col0 + wn * WN + l31;
     switch (epi) {
         case EPI_BIAS: store_tile_out<EPI_BIAS, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
@@ -297,6 +302,7 @@ int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb,
     {
         static const int stagger_env = [] { const char* e = getenv("D2S_GEMM_STAGGER"); return e ? atoi(e) : 0; }();   // experiment knob; measured: no gain
         p.stagger = stagger_env;
+        p.vec_epilogue = 0;
     }
     const int alay = layout == 2 ? 1 : 0, blay = layout == 0 ? 0 : 1;
     p.vecA = aligned16(A) && (lda % 4 == 0) && (alay == 0 ? (K % 4 == 0) : (M % 4 == 0));
@@ -331,6 +337,10 @@ int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb,
         p.remap_rows_per_img = 0;
     } else if (accumulate) {
         p.epi = EPI_ACCUM;
+    }
+    {
+        static const int vec_epi_env = [] { const char* e = getenv("D2S_GEMM_VEC_EPILOGUE"); return e ? atoi(e) : 1; }();
+        p.vec_epilogue = (vec_epi_env && epilogue_vec_ok(p) && (p.slab_stride % 4 == 0)) ? 1 : 0;
     }
     dim3 grid(tiles, 1, slices), block(256);
     if (layout == 0) launch_gemm<0, 0>(tile, grid, stream, p);

@@ -125,6 +125,15 @@ __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, co
 
 struct PieceArgs { const __bf16* Ap; const __bf16* Bp; int Kp; };
 
+#ifdef D2S_STAMPS   // diagnostic build only: per-workgroup {entry, loop begin, loop end, exit} in 100 MHz ticks + cycles of the loop
+__device__ unsigned long long g_stamps[8 * 32768];
+#define STAMP(i) if (tid == 0 && blockIdx.x < 32768) g_stamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime()
+#define STAMPC(i) if (tid == 0 && blockIdx.x < 32768) g_stamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(i)
+#define STAMPC(i)
+#endif
+
 template <int SPLIT, int BK>
 __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, PieceArgs q) {
     constexpr int SBK = BK, PITCH = BK + 8;   // LDS row pitch in bf16: 80 B (BK 32) / 48 B (BK 16), both conflict-free for b128 reads
@@ -133,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, Piec
     __bf16* Bs = As + SPLIT * SBM * PITCH;               // [SPLIT][128][PITCH]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    STAMP(0);
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
     const int nbm = (p.M + SBM - 1) / SBM, nbn = (p.N + SBN - 1) / SBN;
@@ -157,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, Piec
     load_pieces<SPLIT, BK>(q.Ap, p.M, q.Kp, row0, 0, tid, ra);
     load_pieces<SPLIT, BK>(q.Bp, p.N, q.Kp, col0, 0, tid, rb);
 
+    STAMP(1); STAMPC(4);
     for (int kt = 0; kt < nk; ++kt) {
         store_pieces<SPLIT, BK>(As, tid, ra);
         store_pieces<SPLIT, BK>(Bs, tid, rb);
@@ -193,6 +204,11 @@ __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, Piec
         __syncthreads();
     }
 
+    STAMP(2); STAMPC(5);
+    if (p.vec_epilogue) {   // LDS is free after the loop's final barrier; each wave uses its own staging buffer
+        float* stage = reinterpret_cast<float*>(smem_raw) + wave * epi_stage_floats(2);
+        store_tile_dispatch_lds<2, 2>(p.epi, p, p.C, acc, row0 + wm * 64, col0 + wn * 64, lane, stage);
+    } else {
     const int mbase = row0 + wm * 64, nbase = col0 + wn * 64 + l31;
     switch (p.epi) {
         case EPI_BIAS: store_tile_out<EPI_BIAS, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
@@ -205,6 +221,11 @@ __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, Piec
         case EPI_ACCUM: store_tile_out<EPI_ACCUM, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
         default: store_tile_out<EPI_NONE, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
     }
+    }
+#ifdef D2S_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);   // stores issued and acknowledged
+    STAMP(3);
+#endif
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -236,14 +257,23 @@ int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace,
         else hipLaunchKernelGGL(split_rows_kernel<1>, dim3((unsigned)((eb + 255) / 256)), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
     }
     const int tiles = ((p.M + SBM - 1) / SBM) * ((p.N + SBN - 1) / SBN);
-    static const int bk = [] { const char* e = getenv("D2S_SPLIT_BK"); return (e && atoi(e) == 32) ? 32 : 16; }();
-    const size_t lds = (size_t)split * (SBM + SBN) * (bk + 8) * sizeof(__bf16);
+    static const int bk = [] { const char* e = getenv("D2S_SPLIT_BK"); return (e && atoi(e) == 16) ? 16 : 32; }();   // 32 measured faster than 16 on every model shape
+    size_t lds = (size_t)split * (SBM + SBN) * (bk + 8) * sizeof(__bf16);
+    if (lds < 4 * epi_stage_floats(2) * sizeof(float)) lds = 4 * epi_stage_floats(2) * sizeof(float);
+    GemmArgs pv = p;
+    pv.vec_epilogue = epilogue_vec_ok(p) ? 1 : 0;
     PieceArgs q{Ap, Bp, Kp};
-    if (split == 3 && bk == 32) hipLaunchKernelGGL((gemm_pieces_nt_kernel<3, 32>), dim3(tiles), block, lds, stream, p, q);
-    else if (split == 3) hipLaunchKernelGGL((gemm_pieces_nt_kernel<3, 16>), dim3(tiles), block, lds, stream, p, q);
-    else if (bk == 32) hipLaunchKernelGGL((gemm_pieces_nt_kernel<1, 32>), dim3(tiles), block, lds, stream, p, q);
-    else hipLaunchKernelGGL((gemm_pieces_nt_kernel<1, 16>), dim3(tiles), block, lds, stream, p, q);
+    if (split == 3 && bk == 32) hipLaunchKernelGGL((gemm_pieces_nt_kernel<3, 32>), dim3(tiles), block, lds, stream, pv, q);
+    else if (split == 3) hipLaunchKernelGGL((gemm_pieces_nt_kernel<3, 16>), dim3(tiles), block, lds, stream, pv, q);
+    else if (bk == 32) hipLaunchKernelGGL((gemm_pieces_nt_kernel<1, 32>), dim3(tiles), block, lds, stream, pv, q);
+    else hipLaunchKernelGGL((gemm_pieces_nt_kernel<1, 16>), dim3(tiles), block, lds, stream, pv, q);
     return d2s_check_launch();
 }
+
+#ifdef D2S_STAMPS
+extern "C" int d2s_debug_read_stamps(unsigned long long* host_out, int n_wg) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), (size_t)n_wg * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // namespace d2s_gemm

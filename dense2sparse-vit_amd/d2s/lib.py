@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libd2s_hip.so")
+LIB_PATH = os.environ.get("D2S_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libd2s_hip.so")   # override: diagnostic builds
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
 
