@@ -31,6 +31,8 @@ struct GemmArgs {
     int remap_rows_per_img; int remap_skip;
     int stagger;       // de-synchronise the first residency round (speed only)
     int vec_epilogue;  // 16-byte LDS-staged epilogue allowed (see epilogue_vec_ok)
+    float* colsum;     // TN only: column sums of the A operand (bias gradient), one slab of M floats per K slice; may be null
+    int colsum_accumulate;
 };
 
 template <int EPI, int MT, int NT>

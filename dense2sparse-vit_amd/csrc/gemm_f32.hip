@@ -132,9 +132,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // wgrad (ALAY 1): the bn == 0 workgroups also sum their A (= dy) tiles over the token rows - the bias gradient - from the
+    // registers the tile passes through anyway, instead of a separate pass that re-reads dy from HBM
+    const bool do_colsum = (ALAY == 1) && p.colsum != nullptr && bn == 0;
+    f32x4 csum[BM / 64];
+#pragma unroll
+    for (int i = 0; i < BM / 64; ++i) csum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
     f32x4 ra[BM / 64], rb[BN / 64];
     if (nk > 0) {
         load_tile<ALAY, BM>(p.A, p.lda, row0, kbeg, p.M, kend, p.vecA, tid, ra);
+        if (ALAY == 1 && do_colsum) {
+#pragma unroll
+            for (int i = 0; i < BM / 64; ++i) csum[i] += ra[i];
+        }
         load_tile<BLAY, BN>(p.B, p.ldb, col0, kbeg, p.N, kend, p.vecB, tid, rb);
         store_tile<ALAY, BM>(As, tid, ra);
         store_tile<BLAY, BN>(Bs, tid, rb);
@@ -166,6 +177,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         if (kt + 1 < nk) {
             store_tile<ALAY, BM>(As + (cur ^ 1) * BK * BM, tid, ra);
             store_tile<BLAY, BN>(Bs + (cur ^ 1) * BK * BN, tid, rb);
+            if (ALAY == 1 && do_colsum) {
+#pragma unroll
+                for (int i = 0; i < BM / 64; ++i) csum[i] += ra[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    if (ALAY == 1 && do_colsum) {   // block-uniform.  Thread t holds rows (t % CH)*4..+3 for k rows t / CH (+ multiples of G)
+        constexpr int CH = BM / 4, G = 256 / CH;
+        f32x4 t = csum[0];
+#pragma unroll
+        for (int i = 1; i < BM / 64; ++i) t += csum[i];
+        *reinterpret_cast<f32x4*>(&smem[(tid / CH) * BM + (tid % CH) * 4]) = t;
+        __syncthreads();
+        if (tid < BM && row0 + tid < p.M) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) s += smem[g * BM + tid];
+            float* o = p.colsum + (long)blockIdx.z * p.M + row0 + tid;
+            *o = (gridDim.z == 1 && p.colsum_accumulate) ? *o + s : s;
         }
         __syncthreads();
     }
@@ -195,10 +227,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 // Deterministic split-K combine: C (+)= sum over slabs in slab order.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C,
                                                             long ldc, int M, int N, int slabs, long slab_stride,
-                                                            int accumulate) {
+                                                            int accumulate, const float* __restrict__ colsum_ws,
+                                                            float* __restrict__ colsum_out) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)M * N;
-    if (idx >= total) return;
+    if (idx >= total) {   // tail threads fold the fused bias-gradient slabs
+        const long m = idx - total;
+        if (colsum_out && m < M) {
+            float s = 0.f;
+            for (int z = 0; z < slabs; ++z) s += colsum_ws[(long)z * M + m];
+            colsum_out[m] = accumulate ? colsum_out[m] + s : s;
+        }
+        return;
+    }
     const int m = (int)(idx / N), n = (int)(idx % N);
     float s = 0.f;
     for (int z = 0; z < slabs; ++z) s += ws[(long)z * slab_stride + (long)m * N + n];
@@ -281,15 +322,15 @@ size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K) {
     const int max_slices = (K + 255) / 256;
     if (slices > max_slices) slices = max_slices;
     if (slices <= 1) return 0;
-    return (size_t)slices * M * N * sizeof(float);
+    return ((size_t)slices * M * N + (size_t)slices * M) * sizeof(float);   // C slabs + fused bias-gradient slabs
 }
 
 // layout 0 = NT (A[M,K], B[N,K]); 1 = NN (A[M,K], B[K,N]); 2 = TN (A[K,M], B[K,N]).
 // epilogue: see enum Epi.  accumulate != 0 (TN only): C += result.  remap_*: see GemmArgs.
-int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
-                 int K, int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, int aux_rows,
-                 int remap_rows_per_img, int remap_skip, int accumulate, void* workspace, size_t workspace_bytes,
-                 hipStream_t stream) {
+static int gemm_impl(int layout, const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                     int K, int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, int aux_rows,
+                     int remap_rows_per_img, int remap_skip, int accumulate, void* workspace, size_t workspace_bytes,
+                     hipStream_t stream, float* colsum_out) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || layout < 0 || layout > 2) return D2S_ERR_ARG;
     if ((epilogue == EPI_BIAS_RESID || epilogue == EPI_MUL_GELU_GRAD || epilogue == EPI_MUL_RELU_MASK ||
          epilogue == EPI_BIAS_ROWADD) && !aux)
@@ -299,6 +340,7 @@ int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb,
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
     p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.aux_rows = aux_rows > 0 ? aux_rows : 1;
     p.remap_rows_per_img = remap_rows_per_img; p.remap_skip = remap_skip;
+    p.colsum = nullptr; p.colsum_accumulate = accumulate;
     {
         static const int stagger_env = [] { const char* e = getenv("D2S_GEMM_STAGGER"); return e ? atoi(e) : 0; }();   // experiment knob; measured: no gain
         p.stagger = stagger_env;
@@ -329,14 +371,16 @@ int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb,
     p.slab_stride = 0;
     float* realC = C;
     if (slices > 1) {
-        const size_t need = (size_t)slices * M * N * sizeof(float);
+        const size_t need = ((size_t)slices * M * N + (size_t)slices * M) * sizeof(float);
         if (!workspace || workspace_bytes < need) return D2S_ERR_WORKSPACE;
         p.C = static_cast<float*>(workspace);
         p.ldc = N;
         p.slab_stride = (long)M * N;
         p.remap_rows_per_img = 0;
-    } else if (accumulate) {
-        p.epi = EPI_ACCUM;
+        if (colsum_out) p.colsum = static_cast<float*>(workspace) + (size_t)slices * M * N;
+    } else {
+        if (accumulate) p.epi = EPI_ACCUM;
+        p.colsum = colsum_out;
     }
     {
         static const int vec_epi_env = [] { const char* e = getenv("D2S_GEMM_VEC_EPILOGUE"); return e ? atoi(e) : 1; }();
@@ -347,11 +391,31 @@ int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb,
     else if (layout == 1) launch_gemm<0, 1>(tile, grid, stream, p);
     else launch_gemm<1, 1>(tile, grid, stream, p);
     if (slices > 1) {
-        const long total = (long)M * N;
+        const long total = (long)M * N + (colsum_out ? M : 0);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), block, 0, stream,
-                           static_cast<const float*>(workspace), realC, ldc, M, N, slices, (long)M * N, accumulate);
+                           static_cast<const float*>(workspace), realC, ldc, M, N, slices, (long)M * N, accumulate,
+                           p.colsum, colsum_out);
     }
     return d2s_check_launch();
+}
+
+int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                 int K, int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, int aux_rows,
+                 int remap_rows_per_img, int remap_skip, int accumulate, void* workspace, size_t workspace_bytes,
+                 hipStream_t stream) {
+    return gemm_impl(layout, A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, aux, ldaux, aux_out, aux_rows, remap_rows_per_img,
+                     remap_skip, accumulate, workspace, workspace_bytes, stream, nullptr);
+}
+
+// nn.Linear backward w.r.t. its parameters in one pass over dy:  dW[n_out, n_in] (+)= dy^T x,  db[n_out] (+)= column sums of dy.
+// The bias gradient is folded out of the dy tiles the GEMM streams through its registers anyway (no second read of dy).
+size_t d2s_linear_wgrad_workspace_bytes(int tokens, int n_out, int n_in) {
+    return d2s_gemm_f32_workspace_bytes(2, n_out, n_in, tokens);
+}
+int d2s_linear_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, float* db, int tokens,
+                         int n_out, int n_in, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return gemm_impl(2, dy, lddy, x, ldx, dW, lddw, n_out, n_in, tokens, EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0,
+                     accumulate, workspace, workspace_bytes, stream, db);
 }
 
 size_t d2s_colsum_workspace_bytes(int M, int N) {

@@ -50,11 +50,12 @@ class EmbedFn(torch.autograd.Function):
         dw = db = dcls = dpos = None
         if _need(ctx, 1) or _need(ctx, 2):
             gp = ops.copy_rows(g, ops.skip_cls_map(T + 1, D), B * T, D)
+            db = ops.grad_buffer(proj_b) if _need(ctx, 2) else None
             if _need(ctx, 1):
                 dw = ops.grad_buffer(proj_w)
-                ops.linear_wgrad(gp, col, dw.view(D, Kc))
-            if _need(ctx, 2):
-                db = ops.colsum(gp, ops.grad_buffer(proj_b))
+                ops.linear_wgrad(gp, col, dw.view(D, Kc), db=db)
+            elif db is not None:
+                ops.colsum(gp, db)
         if _need(ctx, 3) or _need(ctx, 4):
             dpos = ops.grad_buffer(pos_embed)
             ops.batch_sum(g, dpos, B, (T + 1) * D, (T + 1) * D)
@@ -108,15 +109,9 @@ class BlockFn(torch.autograd.Function):
         new = ops.grad_buffer
 
         # ---- MLP branch ----
-        if wants[11]:
-            grads[11] = ops.linear_wgrad(gy, h, new(fc2w))
-        if wants[12]:
-            grads[12] = ops.colsum(gy, new(fc2b))
+        grads[11], grads[12] = ops.linear_param_grads(gy, h, fc2w, fc2b, wants[11], wants[12])
         dz = ops.linear_dgrad(gy, fc2w, epi=ops.EPI_MUL_GELU_GRAD, aux=z)
-        if wants[9]:
-            grads[9] = ops.linear_wgrad(dz, ln2, new(fc1w))
-        if wants[10]:
-            grads[10] = ops.colsum(dz, new(fc1b))
+        grads[9], grads[10] = ops.linear_param_grads(dz, ln2, fc1w, fc1b, wants[9], wants[10])
         dln2 = ops.linear_dgrad(dz, fc1w)
         g1 = torch.empty((M, D), dtype=torch.float32, device=dev)
         dn2w = new(n2w) if (wants[7] or wants[8]) else None
@@ -124,16 +119,10 @@ class BlockFn(torch.autograd.Function):
         ops.layernorm_bwd(x1, cmap, dln2, n2w, mean2, rstd2, g1, gy, dn2w, dn2b, M, D)
         grads[7], grads[8] = (dn2w if wants[7] else None), (dn2b if wants[8] else None)
         # ---- attention branch ----
-        if wants[5]:
-            grads[5] = ops.linear_wgrad(g1, ao, new(projw))
-        if wants[6]:
-            grads[6] = ops.colsum(g1, new(projb))
+        grads[5], grads[6] = ops.linear_param_grads(g1, ao, projw, projb, wants[5], wants[6])
         dao = ops.linear_dgrad(g1, projw)
         dqkv = ops.attn_bwd(qkv, ao, dao, lse, B, n, heads, scale)
-        if wants[3]:
-            grads[3] = ops.linear_wgrad(dqkv, ln1, new(qkvw))
-        if wants[4]:
-            grads[4] = ops.colsum(dqkv, new(qkvb))
+        grads[3], grads[4] = ops.linear_param_grads(dqkv, ln1, qkvw, qkvb, wants[3], wants[4])
         gx = None
         if wants[0] or wants[1] or wants[2]:
             dln1 = ops.linear_dgrad(dqkv, qkvw)
@@ -197,10 +186,7 @@ class PredictorFn(torch.autograd.Function):
             base = 4 + 4 * j
             width = cur.shape[1]
             # d is the gradient w.r.t. the pre-activation of layer j's Linear (the ReLU mask was applied upstream)
-            if want[base + 2]:
-                grads[base + 2] = ops.linear_wgrad(d, ln, ops.grad_buffer(fw))
-            if want[base + 3]:
-                grads[base + 3] = ops.colsum(d, ops.grad_buffer(fb))
+            grads[base + 2], grads[base + 3] = ops.linear_param_grads(d, ln, fw, fb, want[base + 2], want[base + 3])
             dln = ops.linear_dgrad(d, fw)
             dcur = torch.empty((M, width), dtype=torch.float32, device=dev)
             dlw = ops.grad_buffer(lw) if (want[base] or want[base + 1]) else None
@@ -212,10 +198,7 @@ class PredictorFn(torch.autograd.Function):
             grads[base], grads[base + 1] = (dlw if want[base] else None), (dlb if want[base + 1] else None)
             d = dcur
         dz1 = ops.half_mean_concat(d, B, T, C, relu_mask_src=a1)
-        if want[2]:
-            grads[2] = ops.linear_wgrad(dz1, h0, ops.grad_buffer(params[2]))
-        if want[3]:
-            grads[3] = ops.colsum(dz1, ops.grad_buffer(params[3]))
+        grads[2], grads[3] = ops.linear_param_grads(dz1, h0, params[2], params[3], want[2], want[3])
         gx = None
         if _need(ctx, 0) or want[0] or want[1]:
             dh0 = ops.linear_dgrad(dz1, params[2])
@@ -275,11 +258,8 @@ class HeadFn(torch.autograd.Function):
             glogits = glogits.contiguous()
             cls_g = ops.linear_dgrad(glogits, hw)
             ops.copy_rows(cls_g, ops.contiguous_map(B, D), B, D, dst=gfull, dst_map=(1, n * D, D, 0))
-            if _need(ctx, 3):
-                cls_rows = ops.copy_rows(xn, (1, n * D, D, 0), B, D)
-                dhw = ops.linear_wgrad(glogits, cls_rows, ops.grad_buffer(hw))
-            if _need(ctx, 4):
-                dhb = ops.colsum(glogits, ops.grad_buffer(hb))
+            cls_rows = ops.copy_rows(xn, (1, n * D, D, 0), B, D) if _need(ctx, 3) else None
+            dhw, dhb = ops.linear_param_grads(glogits, cls_rows, hw, hb, _need(ctx, 3), _need(ctx, 4))
         gx = torch.empty((M, D), dtype=torch.float32, device=dev)
         dnw = ops.grad_buffer(nw) if (_need(ctx, 1) or _need(ctx, 2)) else None
         dnb = ops.grad_buffer(nb) if dnw is not None else None
@@ -415,8 +395,12 @@ class LinearFn(torch.autograd.Function):
         elif ctx.act == "relu":
             g = ops.act_grad(g, z, "relu")
         dx = ops.linear_dgrad(g, w) if ctx.needs_input_grad[0] else None
-        dw = ops.linear_wgrad(g, x, torch.empty_like(w)) if ctx.needs_input_grad[1] else None
-        db = ops.colsum(g, torch.empty((w.shape[0],), dtype=torch.float32, device=g.device)) if ctx.needs_input_grad[2] else None
+        db = torch.empty((w.shape[0],), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = ops.linear_wgrad(g, x, torch.empty_like(w), db=db)
+        elif db is not None:
+            ops.colsum(g, db)
         return dx, dw, db, None
 
 

@@ -55,10 +55,7 @@ class SmallPredictorFn(torch.autograd.Function):
             lw, lb, fw, fb = params[4 + 4 * j: 8 + 4 * j]
             base = 4 + 4 * j
             width = cur.shape[1]
-            if want[base + 2]:
-                grads[base + 2] = ops.linear_wgrad(d, ln, ops.grad_buffer(fw))
-            if want[base + 3]:
-                grads[base + 3] = ops.colsum(d, ops.grad_buffer(fb))
+            grads[base + 2], grads[base + 3] = ops.linear_param_grads(d, ln, fw, fb, want[base + 2], want[base + 3])
             dln = ops.linear_dgrad(d, fw)
             dcur = torch.empty((M, width), dtype=torch.float32, device=dev)
             dlw = ops.grad_buffer(lw) if (want[base] or want[base + 1]) else None
@@ -70,10 +67,7 @@ class SmallPredictorFn(torch.autograd.Function):
             else:
                 d = dcur
         dz1 = ops.act_grad(ops.half_mean_concat(d, B, T, C), z1, "gelu")
-        if want[2]:
-            grads[2] = ops.linear_wgrad(dz1, h0, ops.grad_buffer(params[2]))
-        if want[3]:
-            grads[3] = ops.colsum(dz1, ops.grad_buffer(params[3]))
+        grads[2], grads[3] = ops.linear_param_grads(dz1, h0, params[2], params[3], want[2], want[3])
         gx = None
         if ctx.needs_input_grad[0] or want[0] or want[1]:
             dh0 = ops.linear_dgrad(dz1, params[2])

@@ -82,15 +82,9 @@ def _mlp_tail_bwd(gout, y, saved, n2w, n2b, f1w, f1b, f2w, f2b, want):
     h2, mean2, rstd2, z, g_ = saved
     M, E = y.shape
     grads = [None] * 6
-    if want[4]:
-        grads[4] = ops.linear_wgrad(gout, g_, ops.grad_buffer(f2w))
-    if want[5]:
-        grads[5] = ops.colsum(gout, ops.grad_buffer(f2b))
+    grads[4], grads[5] = ops.linear_param_grads(gout, g_, f2w, f2b, want[4], want[5])
     dz = ops.linear_dgrad(gout, f2w, epi=ops.EPI_MUL_GELU_GRAD, aux=z)
-    if want[2]:
-        grads[2] = ops.linear_wgrad(dz, h2, ops.grad_buffer(f1w))
-    if want[3]:
-        grads[3] = ops.colsum(dz, ops.grad_buffer(f1b))
+    grads[2], grads[3] = ops.linear_param_grads(dz, h2, f1w, f1b, want[2], want[3])
     dh2 = ops.linear_dgrad(dz, f1w)
     gy = torch.empty((M, E), dtype=torch.float32, device=gout.device)
     dw = ops.grad_buffer(n2w) if (want[0] or want[1]) else None
@@ -131,16 +125,10 @@ class TokenPerformerFn(torch.autograd.Function):
         gy, tg = _mlp_tail_bwd(gout, y, tail, n2w, n2b, f1w, f1b, f2w, f2b, want[7:13])
         grads = [None] * 14
         grads[7:13] = tg
-        if want[5]:
-            grads[5] = ops.linear_wgrad(gy, ya, ops.grad_buffer(projw))
-        if want[6]:
-            grads[6] = ops.colsum(gy, ops.grad_buffer(projb))
+        grads[5], grads[6] = ops.linear_param_grads(gy, ya, projw, projb, want[5], want[6])
         dya = ops.linear_dgrad(gy, projw)
         dkqv = ops.performer_attn_bwd(kqv, wfeat, ya, kp, qp, A, ksum, D, dya, gy, B, T)
-        if want[3]:
-            grads[3] = ops.linear_wgrad(dkqv, h, ops.grad_buffer(kqvw))
-        if want[4]:
-            grads[4] = ops.colsum(dkqv, ops.grad_buffer(kqvb))
+        grads[3], grads[4] = ops.linear_param_grads(dkqv, h, kqvw, kqvb, want[3], want[4])
         if want[0] or want[1] or want[2]:
             dh = ops.linear_dgrad(dkqv, kqvw)
             dx = torch.empty((M, dim), dtype=torch.float32, device=gout.device)
@@ -183,18 +171,12 @@ class TokenTransformerFn(torch.autograd.Function):
         gy, tg = _mlp_tail_bwd(gout, y, tail, n2w, n2b, f1w, f1b, f2w, f2b, want[7:13])
         grads = [None] * 13
         grads[7:13] = tg
-        if want[5]:
-            grads[5] = ops.linear_wgrad(gy, ao, ops.grad_buffer(projw))
-        if want[6]:
-            grads[6] = ops.colsum(gy, ops.grad_buffer(projb))
+        grads[5], grads[6] = ops.linear_param_grads(gy, ao, projw, projb, want[5], want[6])
         dao = ops.linear_dgrad(gy, projw)
         dqkv = ops.attn_bwd(qkv, ao, dao, lse, B, T, 1, scale)
         # skip connection through v: dqkv[:, 128:192] += gy
         ops.copy_rows(gy, ops.contiguous_map(M, 64), M, 64, dst=dqkv, dst_map=(M, 0, 192, 128), accumulate=True)
-        if want[3]:
-            grads[3] = ops.linear_wgrad(dqkv, h, ops.grad_buffer(qkvw))
-        if want[4] and qkvb is not None:
-            grads[4] = ops.colsum(dqkv, ops.grad_buffer(qkvb))
+        grads[3], grads[4] = ops.linear_param_grads(dqkv, h, qkvw, qkvb, want[3], want[4])
         if want[0] or want[1] or want[2]:
             dh = ops.linear_dgrad(dqkv, qkvw)
             dx = torch.empty((M, dim), dtype=torch.float32, device=gout.device)

@@ -60,12 +60,27 @@ def linear_dgrad(dy, W, epi=EPI_NONE, aux=None, out=None):
     return gemm(NN, dy, N, W, K, out, K, M, K, N, epi, None, aux, K if aux is not None else 0)
 
 
-def linear_wgrad(dy, x, dW, accumulate=False):
-    """dW[N,K] (+)= dy[M,N]^T @ x[M,K]."""
+def linear_wgrad(dy, x, dW, accumulate=False, db=None):
+    """dW[N,K] (+)= dy[M,N]^T @ x[M,K]; with db also db[N] (+)= dy.sum(0), folded into the same pass over dy."""
     _f32(dy), _f32(x), _f32(dW)
     M, N = dy.shape
     K = x.shape[1]
-    return gemm(TN, dy, N, x, K, dW, K, N, K, M, accumulate=accumulate)
+    need = lib.query("d2s_linear_wgrad_workspace_bytes", M, N, K)
+    ws = workspace(need, dW.device) if need else None
+    lib.call("d2s_linear_wgrad_f32", lib.ptr(dy), N, lib.ptr(x), K, lib.ptr(dW), K, lib.ptr(db), M, N, K, int(accumulate),
+             lib.ptr(ws), ws.numel() if ws is not None else 0)
+    return dW
+
+
+def linear_param_grads(dy, x, W, b, want_w=True, want_b=True, accumulate=False):
+    """(dW, db) of a Linear into fresh arena-backed buffers: one fused pass when both are wanted."""
+    dW = grad_buffer(W) if want_w else None
+    db = grad_buffer(b) if (want_b and b is not None) else None
+    if dW is not None:
+        linear_wgrad(dy, x, dW, accumulate=accumulate, db=db)
+    elif db is not None:
+        colsum(dy, db, accumulate=accumulate)
+    return dW, db
 
 
 def colsum(x, out, accumulate=False):

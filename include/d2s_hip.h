@@ -49,7 +49,13 @@ int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb,
                  int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, int aux_rows,
                  int remap_rows_per_img, int remap_skip, int accumulate, void* workspace, size_t workspace_bytes,
                  d2s_stream_t stream);
-/* out[n] (+)= sum_m X[m][n]: bias gradients of every Linear. */
+/* nn.Linear parameter gradients in one pass over dy (autograd of F.linear at vit_models/dynamic_vit.py:169-175,218,231,491-531):
+ * dW[n_out,n_in] (+)= dy[tokens,n_out]^T x[tokens,n_in];  db[n_out] (+)= column sums of dy (db may be NULL).  Exact fp32 MFMA,
+ * deterministic split-K over the token rows; the bias gradient is folded out of the dy tiles the GEMM streams anyway. */
+size_t d2s_linear_wgrad_workspace_bytes(int tokens, int n_out, int n_in);
+int d2s_linear_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, float* db, int tokens,
+                         int n_out, int n_in, int accumulate, void* workspace, size_t workspace_bytes, d2s_stream_t stream);
+/* out[n] (+)= sum_m X[m][n]: bias gradients where no weight gradient is wanted. */
 size_t d2s_colsum_workspace_bytes(int M, int N);
 int d2s_colsum_f32(const float* X, long ldx, int M, int N, float* out, int accumulate, void* workspace,
                    size_t workspace_bytes, d2s_stream_t stream);

@@ -1,3 +1,4 @@
+import math
 """GPU tier, per-kernel parity: every HIP entry point (called through the C ABI) against the CPU oracle / plain torch
 fp32 CPU ops on the same seeded inputs.  Integer outputs must be bit-exact; floating point within the tolerance
 written at each assert."""
@@ -79,6 +80,29 @@ def test_gemm_wgrad_and_colsum(ops, M, N, K):
     np.testing.assert_allclose(db.cpu().numpy(), dy.double().sum(0).float().numpy(), rtol=1e-4, atol=1e-4)
     ops.colsum(dy.to(_dev()), db, accumulate=True)
     np.testing.assert_allclose(db.cpu().numpy(), 2 * dy.double().sum(0).float().numpy(), rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("tokens,n_out,n_in", [(1000, 96, 192), (197 * 3, 384, 384), (130, 10, 24), (4096, 200, 72), (25, 1, 96)])
+def test_linear_wgrad_fused_bias_grad(ops, tokens, n_out, n_in):
+    """d2s_linear_wgrad_f32: dW and db from ONE pass over dy (split-K slabs and the single-slice path), plus accumulate."""
+    g = torch.Generator().manual_seed(tokens + n_out)
+    dy = torch.randn(tokens, n_out, generator=g)
+    x = torch.randn(tokens, n_in, generator=g)
+    dW = torch.empty(n_out, n_in, device=_dev())
+    db = torch.empty(n_out, device=_dev())
+    ops.linear_wgrad(dy.to(_dev()), x.to(_dev()), dW, db=db)
+    ref_w = (dy.double().t() @ x.double())
+    ref_b = dy.double().sum(0)
+    tol = 2e-6 * math.sqrt(tokens)
+    assert (dW.cpu().double() - ref_w).abs().max() <= tol * ref_w.abs().max().clamp_min(1.0)
+    assert (db.cpu().double() - ref_b).abs().max() <= tol * ref_b.abs().max().clamp_min(1.0)
+    ops.linear_wgrad(dy.to(_dev()), x.to(_dev()), dW, db=db, accumulate=True)
+    assert (dW.cpu().double() - 2 * ref_w).abs().max() <= 2 * tol * ref_w.abs().max().clamp_min(1.0)
+    assert (db.cpu().double() - 2 * ref_b).abs().max() <= 2 * tol * ref_b.abs().max().clamp_min(1.0)
+    # without db the entry leaves nothing else behind
+    dW2 = torch.empty_like(dW)
+    ops.linear_wgrad(dy.to(_dev()), x.to(_dev()), dW2)
+    assert torch.equal(dW2.cpu() * 2, dW.cpu()) or (dW2.cpu().double() - ref_w).abs().max() <= tol * ref_w.abs().max().clamp_min(1.0)
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
