@@ -83,6 +83,19 @@ class KernelTimer:
             timer.records.setdefault(("gather_pack", ""), []).append((s, e, B * (2.0 * (k + 1) * D * 4 + 8.0 * k)))
             return out
 
+        orig_wgrad = ops.linear_wgrad
+
+        def linear_wgrad(dy, x, dW, *a, **kw):
+            if not timer.enabled:
+                return orig_wgrad(dy, x, dW, *a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = orig_wgrad(dy, x, dW, *a, **kw)
+            e.record()
+            timer.records.setdefault(("gemm_f32", "TN"), []).append((s, e, 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1]))
+            return out
+
+        ops.linear_wgrad = linear_wgrad
         orig_scatter = ops.scatter_unpack
 
         def scatter_unpack(g, ids, n):
@@ -114,6 +127,22 @@ class KernelTimer:
             ms = sum(s.elapsed_time(e) for s, e, _ in recs)
             out[key] = dict(launches=len(recs), ms=ms, work=sum(w for _, _, w in recs))
         return out
+
+
+def hbm_copy_gbs(device, mbytes=1024, reps=10):
+    """Device-to-device copy rate in this run (confirm the HBM figure the fractions are priced against): bytes read +
+    bytes written per second of a 1 GiB hipMemcpyAsync D2D."""
+    a = torch.empty(mbytes << 20, dtype=torch.uint8, device=device)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e.record()
+    torch.cuda.synchronize()
+    return round(2.0 * a.numel() * reps / (s.elapsed_time(e) * 1e-3) / 1e9, 1)
 
 
 def build(device, keep, seed=0):
@@ -237,6 +266,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = not args.no_kernel_timing
+    if distributed:
+        ts.reducer.timing = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         info = ts(images, labels)
@@ -297,6 +328,11 @@ def main():
                               "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                               "bytes_per_launch": ga["work"] / ga["launches"], "avg_launch_us": round(1000.0 * ga["ms"] / ga["launches"], 2),
                               "traffic": pmc_traffic("gather_pack_kernel"), "at_batch_2048": gather_large(device)}
+        line["hbm_copy_GBps_measured"] = hbm_copy_gbs(device)
+        if distributed:
+            c = ts.reducer.comm_summary(args.steps)
+            if c:
+                line["comm"] = c
         if n_gpus == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle (bounded sample)")
             line["cpu_baseline"] = cpu_baseline(args.keep)

@@ -176,20 +176,29 @@ class GradReducer:
         self.stream = torch.cuda.Stream() if arena.params.is_cuda else None
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self._hi = arena.total
-        self._works = []
         self.force = False      # rehearsal: issue the collectives even with a single rank
+        self.timing = False     # bench: bracket every collective with events on the side stream
+        self._events, self._exposed, self._bytes, self._launched = [], [], 0, False
 
     def _launch(self, lo):
         hi, self._hi = self._hi, lo
         if (self.world == 1 and not self.force) or lo >= hi:
             return
         buf = self.arena.grads[lo:hi]
-        if self.stream is not None:
-            self.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.stream):
-                self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        else:
-            self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._launched = True
+        if self.stream is None:          # CPU tensors (gloo rehearsal): blocking
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            if self.timing:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()   # stream-level wait: the side
+            if self.timing:                                                                        # stream follows RCCL's stream
+                e1.record()
+                self._events.append((e0, e1))
+                self._bytes += buf.numel() * 4
 
     def ready_from(self, lo):
         """Every gradient at arena offset >= lo is final."""
@@ -199,13 +208,33 @@ class GradReducer:
     def finish(self):
         """Flush the remainder, join, and return 1/world (folded into the optimiser's gradient scale)."""
         self._launch(0)
-        for w in self._works:
-            w.wait()
-        if (self.world > 1 or self.force) and self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
-        self._works = []
+        if self._launched and self.stream is not None:
+            cur = torch.cuda.current_stream()
+            if self.timing:
+                arrived, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                arrived.record(cur)
+                done.record(self.stream)
+                self._exposed.append((arrived, done))
+            cur.wait_stream(self.stream)
+        self._launched = False
         self._hi = self.arena.total
         return 1.0 / self.world
+
+    def comm_summary(self, steps):
+        """Per-step communication figures from the recorded events (call after a device synchronize): bytes all-reduced, time
+        the collectives occupied the side stream, bus bandwidth 2(N-1)/N * bytes / time, and the exposed part = how long the
+        main stream had to wait in finish() after the backward was already done."""
+        if not self._events:
+            return None
+        t_ms = sum(a.elapsed_time(b) for a, b in self._events)
+        exposed = sum(max(0.0, a.elapsed_time(b)) for a, b in self._exposed)
+        n = max(self.world, 1)
+        out = {"allreduce_bytes_per_step": self._bytes / steps, "collectives_per_step": len(self._events) / steps,
+               "allreduce_ms_per_step": round(t_ms / steps, 3), "exposed_ms_per_step": round(exposed / steps, 3),
+               "bus_GBps": round(2.0 * (n - 1) / n * self._bytes / (t_ms * 1e-3) / 1e9, 1) if t_ms > 0 else None,
+               "backend": "nccl (RCCL)", "world": n}
+        self._events, self._exposed, self._bytes = [], [], 0
+        return out
 
 
 class TrainStep:

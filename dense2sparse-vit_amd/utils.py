@@ -64,3 +64,77 @@ class SyntheticLoader:
         for _ in range(self.steps):
             yield (torch.randn((self.batch, 3, self.img, self.img), generator=g, device=self.device),
                    torch.randint(0, self.nc, (self.batch,), generator=g, device=self.device))
+
+
+def parse_args(argv=None):
+    """The reference's command line (utils.py:182-317): same flag names, types and defaults, so job scripts written for the
+    reference run unchanged.  Data-set / augmentation / tracking flags are accepted and ignored (inputs are synthetic here:
+    no data set or network in the image); four synthetic-run flags are added at the end."""
+    import argparse
+    p = argparse.ArgumentParser(description='Transformers')
+    p.add_argument('--arch', default='deit_small', type=str)
+    p.add_argument('--is-sbatch', action='store_true', default=False)
+    p.add_argument('--wandb', action='store_true', default=False)
+    p.add_argument('--save-path', default='test_imgs/')
+    p.add_argument('--model-name', type=str, default='deit_small_patch16_224')
+    p.add_argument('--patch-size', default=16)
+    p.add_argument('--use-shape', action='store_true', default=False)
+    p.add_argument('--batch-size', default=64, type=int)
+    p.add_argument('--epochs', default=25, type=int)
+    p.add_argument('--use-dp', action='store_true', default=False)
+    p.add_argument('--use-ddp', action='store_true', default=False)
+    p.add_argument('--imgnet-val-dir', type=str, default="")
+    p.add_argument('--weight-decay', type=float, default=0.05)
+    p.add_argument('--lr', type=float, default=5e-4)
+    p.add_argument('--warmup-lr', type=float, default=1e-6)
+    p.add_argument('--min-lr', type=float, default=1e-5)
+    p.add_argument('--warmup-steps', default=5, type=int)
+    p.add_argument('--early-exit', action='store_true', default=False)
+    p.add_argument('--pruning-locs', nargs='+', default=[3], type=int)
+    p.add_argument('--keep-ratios', nargs='+', type=float, default=[0.3])
+    p.add_argument('--softmax-temp', default=1.0, type=float)
+    p.add_argument('--use-ratio-loss', action='store_true', default=False)
+    p.add_argument('--ratio-weight', default=2.0, type=float)
+    p.add_argument('--use-token-dist-loss', action='store_true', default=False)
+    p.add_argument('--dist-weight', default=0.5, type=float)
+    p.add_argument('--teacher-cls-loss', action='store_true', default=False)
+    p.add_argument('--cls-weight', default=1.0, type=float)
+    p.add_argument('--topk-selection', action='store_true', default=False)
+    p.add_argument('--mean-heads', action='store_true', default=False)
+    p.add_argument('--random-drop', action='store_true', default=False)
+    p.add_argument('--initial-sigma', default=0.05, type=float)
+    p.add_argument('--attn-selection', action='store_true', default=False)
+    p.add_argument('--cls-from-teacher', action='store_true', default=False)
+    p.add_argument('--freeze-backbone', action='store_true', default=False)
+    p.add_argument('--visualize-patch-drop', action='store_true', default=False)
+    p.add_argument('--visualize-cls-attn-evo', action='store_true', default=False)
+    p.add_argument('--small-predictor', action='store_true', default=False)
+    p.add_argument('--mask-loss-type', default='kl_div', type=str)
+    p.add_argument('--predictor-bn', action='store_true', default=False)
+    p.add_argument('--patch-score-threshold', default=None, type=float)
+    p.add_argument('--color-jitter', type=float, default=0.4)
+    p.add_argument('--aa', type=str, default='rand-m9-mstd0.5-inc1')
+    p.add_argument('--smoothing', type=float, default=0.1)
+    p.add_argument('--train-interpolation', type=str, default='bicubic')
+    p.add_argument('--repeated-aug', action='store_true')
+    p.add_argument('--no-repeated-aug', action='store_false', dest='repeated_aug')
+    p.set_defaults(repeated_aug=True)
+    p.add_argument('--reprob', type=float, default=0.25)
+    p.add_argument('--remode', type=str, default='pixel')
+    p.add_argument('--recount', type=int, default=1)
+    p.add_argument('--resplit', action='store_true', default=False)
+    p.add_argument('--mixup', type=float, default=0.8)
+    p.add_argument('--cutmix', type=float, default=1.0)
+    p.add_argument('--cutmix-minmax', type=float, nargs='+', default=None)
+    p.add_argument('--mixup-prob', type=float, default=1.0)
+    p.add_argument('--mixup-switch-prob', type=float, default=0.5)
+    p.add_argument('--mixup-mode', type=str, default='batch')
+    # ---- additions for synthetic / offline runs (not in the reference) ----
+    p.add_argument('--steps-per-epoch', type=int, default=20, help='synthetic training batches per epoch')
+    p.add_argument('--val-steps', type=int, default=2, help='synthetic validation batches per epoch')
+    p.add_argument('--student-checkpoint', type=str, default=None, help='local DeiT checkpoint for the student (weights_only load)')
+    p.add_argument('--teacher-checkpoint', type=str, default=None, help='local DeiT checkpoint for the teacher (weights_only load)')
+    p.add_argument('--torch-optim', action='store_true', default=False,
+                   help="the reference's recipe (torch.optim.AdamW over get_param_groups) instead of the fused arena step")
+    p.add_argument('--gemm-mode', choices=['exact', 'split', 'bf16'], default='exact')
+    return p.parse_args(argv)

@@ -89,3 +89,37 @@ def test_execution_order_arena_layout():
     i_pred0 = order.index("score_predictor.0.in_conv.0.weight")
     assert order.index("blocks.0.mlp.fc2.bias") < i_pred0 < order.index("blocks.1.norm1.weight")
     assert starts[1] == i_pred0 and starts[0] == order.index("blocks.0.norm1.weight")
+
+
+def test_cli_accepts_every_reference_flag_with_the_same_default():
+    """utils.parse_args mirrors the reference's command line (tests/golden/cli_flags.json: flag names, defaults, types and
+    actions extracted from the text of the reference's utils.py:182-317 by tools/gen_cli_fixture.py)."""
+    import json
+    import utils
+    spec = json.load(open(os.path.join(REPO, "tests", "golden", "cli_flags.json")))["flags"]
+    assert len(spec) >= 50
+    ns = vars(utils.parse_args([]))
+    for ent in spec:
+        flag = ent["flags"][0]
+        dest = ent.get("dest", flag.lstrip("-").replace("-", "_"))
+        assert dest in ns, f"{flag} is not accepted"
+        if "default" in ent and flag != "--imgnet-val-dir":       # the reference's default is its author's home directory
+            assert ns[dest] == ent["default"], (flag, ns[dest], ent["default"])
+        if ent.get("action") == "store_true":
+            assert vars(utils.parse_args([flag]))[dest] is True
+        elif ent.get("type") in ("int", "float") and "nargs" not in ent:
+            v = vars(utils.parse_args([flag, "3"]))[dest]
+            assert v == 3 and type(v).__name__ == ent["type"]
+    a = utils.parse_args(["--pruning-locs", "3", "6", "9", "--keep-ratios", "0.7", "0.5", "0.3", "--no-repeated-aug"])
+    assert a.pruning_locs == [3, 6, 9] and a.keep_ratios == [0.7, 0.5, 0.3] and a.repeated_aug is False
+
+
+def test_cli_rejects_flags_outside_the_path():
+    import mask_predictor
+    import utils
+    for extra in (["--predictor-bn"], ["--patch-score-threshold", "0.9"], ["--early-exit"], ["--mask-loss-type", "bce"], ["--use-dp"]):
+        with pytest.raises(SystemExit, match="not on the accelerated path"):
+            mask_predictor.check_supported(utils.parse_args(extra))
+    a = utils.parse_args([])
+    mask_predictor.check_supported(a)
+    assert a.mixup == 0.0 and a.cutmix == 0.0

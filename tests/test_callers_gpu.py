@@ -58,3 +58,14 @@ def test_evaluate_performance_runs_and_reports():
     for k in ("val_loss", "val_acc", "unpruned_acc", "val_mask_loss", "val_mask_acc_0", "val_mask_acc_1"):
         assert k in m, k
     assert 0.0 <= m["val_acc"] <= 1.0 and m["val_acc"] == m["unpruned_acc"] and np.isfinite(m["val_loss"])
+
+
+def test_mask_predictor_cli_runs_the_epoch_loop(capsys):
+    """The entry script's sequence (factories -> groups -> per epoch LR/freeze schedule -> train -> evaluate) on DeiT-Ti with the
+    reference's flags; epoch 0 is a warm-up epoch (backbone frozen), epoch 1 trains everything."""
+    import mask_predictor
+    best = mask_predictor.main(["--arch", "deit_tiny", "--pruning-locs", "3", "--keep-ratios", "0.5", "--epochs", "2", "--warmup-steps", "1",
+                                "--batch-size", "4", "--steps-per-epoch", "2", "--val-steps", "1", "--topk-selection"])
+    out = capsys.readouterr().out
+    assert 0.0 <= best <= 1.0
+    assert "Epoch 2/2" in out and "Training complete" in out and "train images/s" in out
