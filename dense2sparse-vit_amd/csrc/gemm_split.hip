@@ -119,6 +119,54 @@ __device__ __forceinline__ void store_pieces(__bf16* __restrict__ S, int tid, co
     }
 }
 
+// ---- activation operand straight from fp32 (split in registers on its way to LDS): 4 B/element of L2->CU traffic instead of
+// 2*SPLIT, and no separate split pass over the big operand.  Thread item = 8 consecutive k of one row (two 16-byte loads).
+template <int BK>
+__device__ __forceinline__ void load_a_f32(const float* __restrict__ A, long lda, int M, int K, int row0, int k0, int tid,
+                                           f32x4 (&r)[BK / 16][2]) {
+    constexpr int CH = BK / 8;
+#pragma unroll
+    for (int i = 0; i < BK / 16; ++i) {
+        const int f = tid + i * 256;
+        const int row = row0 + f / CH, k = k0 + (f % CH) * 8;
+        r[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        r[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < M) {
+            const float* p = A + (long)row * lda + k;
+            if (k + 7 < K) {
+                r[i][0] = *reinterpret_cast<const f32x4*>(p);
+                r[i][1] = *reinterpret_cast<const f32x4*>(p + 4);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (k + j < K) r[i][j >> 2][j & 3] = p[j];
+            }
+        }
+    }
+}
+template <int SPLIT, int BK>
+__device__ __forceinline__ void store_a_split(__bf16* __restrict__ S, int tid, const f32x4 (&r)[BK / 16][2]) {
+    constexpr int CH = BK / 8, PITCH = BK + 8;
+#pragma unroll
+    for (int i = 0; i < BK / 16; ++i) {
+        const int f = tid + i * 256;
+        const int row = f / CH, ch = f % CH;
+        bf16x8 h, m, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __bf16 hh, mm = (__bf16)0.f, ll = (__bf16)0.f;
+            if constexpr (SPLIT == 3) split3(r[i][j >> 2][j & 3], hh, mm, ll);
+            else hh = (__bf16)r[i][j >> 2][j & 3];
+            h[j] = hh; m[j] = mm; l[j] = ll;
+        }
+        *reinterpret_cast<bf16x8*>(S + row * PITCH + ch * 8) = h;
+        if constexpr (SPLIT == 3) {
+            *reinterpret_cast<bf16x8*>(S + (128 + row) * PITCH + ch * 8) = m;
+            *reinterpret_cast<bf16x8*>(S + (256 + row) * PITCH + ch * 8) = l;
+        }
+    }
+}
+
 __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -134,7 +182,7 @@ __device__ unsigned long long g_stamps[8 * 32768];
 #define STAMPC(i)
 #endif
 
-template <int SPLIT, int BK>
+template <int SPLIT, int BK, bool AF32>
 __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, PieceArgs q) {
     constexpr int SBK = BK, PITCH = BK + 8;   // LDS row pitch in bf16: 80 B (BK 32) / 48 B (BK 16), both conflict-free for b128 reads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -163,17 +211,21 @@ __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, Piec
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    u32x4 ra[SPLIT][BK / 16], rb[SPLIT][BK / 16];
-    load_pieces<SPLIT, BK>(q.Ap, p.M, q.Kp, row0, 0, tid, ra);
+    u32x4 ra[AF32 ? 1 : SPLIT][BK / 16], rb[SPLIT][BK / 16];
+    f32x4 fa[BK / 16][2];
+    if constexpr (AF32) load_a_f32<BK>(p.A, p.lda, p.M, p.K, row0, 0, tid, fa);
+    else load_pieces<SPLIT, BK>(q.Ap, p.M, q.Kp, row0, 0, tid, ra);
     load_pieces<SPLIT, BK>(q.Bp, p.N, q.Kp, col0, 0, tid, rb);
 
     STAMP(1); STAMPC(4);
     for (int kt = 0; kt < nk; ++kt) {
-        store_pieces<SPLIT, BK>(As, tid, ra);
+        if constexpr (AF32) store_a_split<SPLIT, BK>(As, tid, fa);
+        else store_pieces<SPLIT, BK>(As, tid, ra);
         store_pieces<SPLIT, BK>(Bs, tid, rb);
         __syncthreads();
         if (kt + 1 < nk) {
-            load_pieces<SPLIT, BK>(q.Ap, p.M, q.Kp, row0, (kt + 1) * SBK, tid, ra);
+            if constexpr (AF32) load_a_f32<BK>(p.A, p.lda, p.M, p.K, row0, (kt + 1) * SBK, tid, fa);
+            else load_pieces<SPLIT, BK>(q.Ap, p.M, q.Kp, row0, (kt + 1) * SBK, tid, ra);
             load_pieces<SPLIT, BK>(q.Bp, p.N, q.Kp, col0, (kt + 1) * SBK, tid, rb);
         }
 #pragma unroll
@@ -247,12 +299,18 @@ int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace,
     __bf16* Bp = reinterpret_cast<__bf16*>(static_cast<unsigned char*>(workspace) + align256((size_t)split * p.M * Kp * sizeof(__bf16)));
     const long ea = (long)p.M * (Kp / 4), eb = (long)p.N * (Kp / 4);
     dim3 block(256);
+    // Opt-in (D2S_SPLIT_A_INKERNEL=1): split the activation operand inside the matrix kernel (read as fp32 with 16-byte loads, no
+    // split pass over it).  Alone, a GEMM with <= 4 column tiles runs 9-12 % faster that way and one with 9-12 column tiles 4 %
+    // slower (each panel element is re-split per column tile); inside the training step the pre-split path is 0.5-1 % faster
+    // overall (the freshly written pieces are cache-hot), so it stays the default.
+    static const int a_inkernel_env = [] { const char* e = getenv("D2S_SPLIT_A_INKERNEL"); return e ? atoi(e) : 0; }();
+    const bool af32 = p.vecA && a_inkernel_env != 0;
     if (split == 3) {
-        hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)((ea + 255) / 256)), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
+        if (!af32) hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)((ea + 255) / 256)), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
         if (b_cols) hipLaunchKernelGGL(split_cols_kernel<3>, dim3((p.N + 31) / 32, Kp / 32), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp);
         else hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)((eb + 255) / 256)), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
     } else {
-        hipLaunchKernelGGL(split_rows_kernel<1>, dim3((unsigned)((ea + 255) / 256)), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
+        if (!af32) hipLaunchKernelGGL(split_rows_kernel<1>, dim3((unsigned)((ea + 255) / 256)), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
         if (b_cols) hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.N + 31) / 32, Kp / 32), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp);
         else hipLaunchKernelGGL(split_rows_kernel<1>, dim3((unsigned)((eb + 255) / 256)), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
     }
@@ -263,10 +321,19 @@ int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace,
     GemmArgs pv = p;
     pv.vec_epilogue = epilogue_vec_ok(p) ? 1 : 0;
     PieceArgs q{Ap, Bp, Kp};
-    if (split == 3 && bk == 32) hipLaunchKernelGGL((gemm_pieces_nt_kernel<3, 32>), dim3(tiles), block, lds, stream, pv, q);
-    else if (split == 3) hipLaunchKernelGGL((gemm_pieces_nt_kernel<3, 16>), dim3(tiles), block, lds, stream, pv, q);
-    else if (bk == 32) hipLaunchKernelGGL((gemm_pieces_nt_kernel<1, 32>), dim3(tiles), block, lds, stream, pv, q);
-    else hipLaunchKernelGGL((gemm_pieces_nt_kernel<1, 16>), dim3(tiles), block, lds, stream, pv, q);
+#define D2S_LAUNCH_PIECES(S, K_, F) hipLaunchKernelGGL((gemm_pieces_nt_kernel<S, K_, F>), dim3(tiles), block, lds, stream, pv, q)
+    if (af32) {
+        if (split == 3 && bk == 32) D2S_LAUNCH_PIECES(3, 32, true);
+        else if (split == 3) D2S_LAUNCH_PIECES(3, 16, true);
+        else if (bk == 32) D2S_LAUNCH_PIECES(1, 32, true);
+        else D2S_LAUNCH_PIECES(1, 16, true);
+    } else {
+        if (split == 3 && bk == 32) D2S_LAUNCH_PIECES(3, 32, false);
+        else if (split == 3) D2S_LAUNCH_PIECES(3, 16, false);
+        else if (bk == 32) D2S_LAUNCH_PIECES(1, 32, false);
+        else D2S_LAUNCH_PIECES(1, 16, false);
+    }
+#undef D2S_LAUNCH_PIECES
     return d2s_check_launch();
 }
 

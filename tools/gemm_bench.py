@@ -26,6 +26,9 @@ Mp = B * 196
 shapes += [("NT", Mp, 1536, 384, "pred in_conv"), ("NT", Mp, 768, 1536, "pred l0"), ("NT", Mp, 384, 768, "pred l1"),
            ("NT", Mp, 192, 384, "pred l2"), ("NT", Mp, 96, 192, "pred l3"), ("NT", Mp, 1, 96, "pred l4"),
            ("NT", Mp, 384, 768, "patch embed"), ("NT", 128, 1000, 384, "head")]
+only = os.environ.get("D2S_BENCH_ONLY")     # substring filter on "layout what", e.g. "NT teacher/student n=197 fc1"
+if only:
+    shapes = [t for t in shapes if only in f"{t[0]} {t[4]}"]
 lay = {"NT": 0, "NN": 1, "TN": 2}
 print(f"{'layout':6} {'M':>6} {'N':>5} {'K':>6}  {'us':>8} {'TF/s':>7}  what")
 for L, M, N, K, what in shapes:
