@@ -209,6 +209,26 @@ def gather_large(device, B=2048, n=197, k=98, D=384, iters=20):
     return {"achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "bytes_per_launch": nbytes}
 
 
+def gather_back_to_back(device, B, n=197, k=98, D=384, iters=100, nbuf=16):
+    """The headline-shape gather launched back to back over rotating inputs (16 x 39 MB > the 256 MB Infinity Cache, so reads
+    come from HBM): one event pair around all launches, so the per-launch figure carries launch gaps but not the ~3 us that an
+    event pair adds around a single 10 us kernel in the timed region."""
+    from d2s import ops
+    xs = [torch.randn((B, n, D), device=device) for _ in range(nbuf)]
+    ids = torch.sort(torch.rand((B, n - 1), device=device).argsort(dim=1)[:, :k], dim=1)[0].contiguous()
+    for i in range(3):
+        ops.gather_pack(xs[i], ids)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for i in range(iters):
+        ops.gather_pack(xs[i % nbuf], ids)
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / iters
+    nbytes = B * (2.0 * (k + 1) * D * 4 + 8.0 * k)
+    return {"us_per_launch": round(us, 2), "achieved": round(nbytes / us / 1e3, 1), "unit": "GB/s", "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4)}
+
+
 def log(msg):
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
@@ -327,7 +347,8 @@ def main():
             line["gather"] = {"bound": "hbm", "kernel": "gather_pack_kernel", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                               "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                               "bytes_per_launch": ga["work"] / ga["launches"], "avg_launch_us": round(1000.0 * ga["ms"] / ga["launches"], 2),
-                              "traffic": pmc_traffic("gather_pack_kernel"), "at_batch_2048": gather_large(device)}
+                              "traffic": pmc_traffic("gather_pack_kernel"), "at_batch_2048": gather_large(device),
+                              "back_to_back_hbm_cold": gather_back_to_back(device, args.batch, k=int(196 * args.keep))}
         line["hbm_copy_GBps_measured"] = hbm_copy_gbs(device)
         if distributed:
             c = ts.reducer.comm_summary(args.steps)

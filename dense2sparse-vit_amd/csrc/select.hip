@@ -4,6 +4,7 @@
 // All of it is HBM- or latency-bound integer / byte work: coalesced float4 rows, ids staged once per
 // workgroup in LDS, wave ballots for the ordered compaction.  No atomics anywhere, results are deterministic.
 #include "d2s_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -89,42 +90,33 @@ __global__ __launch_bounds__(256) void select_topk_kernel(const float* __restric
 
 // ---------------------------------------------------------------------------------------------------------
 // gather / pack:   out[b,0] = x[b,0];  out[b,1+j] = x[b,1+ids[b,j]]
-// One workgroup per (image, slab of 16 output rows); ids of the slab staged in LDS; every thread issues all of its
-// 16-byte loads before the first store.
+// One wave per output row, 4 rows per workgroup: the row's source index is one wave-uniform load, then every lane issues all of
+// its 16-byte loads before the first store.  No LDS, no barrier, no integer division per element.  (Measured against the
+// earlier slab-per-workgroup form with LDS-staged indices: 9.9 vs 11.4 us at B=128, k=98, D=384 - tools/gather_bench.py.)
 // ---------------------------------------------------------------------------------------------------------
-constexpr int GROWS = 16;
+constexpr int GROWS = 16;   // rows per workgroup of the scatter kernel below
 __global__ __launch_bounds__(256) void gather_pack_kernel(const float* __restrict__ x, const long long* __restrict__ ids,
-                                                          float* __restrict__ out, int n, int k, int D) {
-    __shared__ int src[GROWS];
-    const int b = blockIdx.y, r0 = blockIdx.x * GROWS, tid = threadIdx.x;
-    const int nrows = min(GROWS, k + 1 - r0);
-    if (tid < nrows) {
-        const int r = r0 + tid;
-        src[tid] = r == 0 ? 0 : 1 + (int)ids[(long)b * k + (r - 1)];
-    }
-    __syncthreads();
+                                                                  float* __restrict__ out, int n, int k, int D, long rows_total) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);      // packed row index over the whole batch
+    if (row >= rows_total) return;
+    const int b = (int)(row / (k + 1)), r = (int)(row - (long)b * (k + 1));
+    const int srow = r == 0 ? 0 : 1 + (int)ids[(long)b * k + (r - 1)];
     const int nvec = D >> 2;
-    const int total = nrows * nvec;
-    const f32x4* xb = reinterpret_cast<const f32x4*>(x + (long)b * n * D);
-    f32x4* ob = reinterpret_cast<f32x4*>(out + ((long)b * (k + 1) + r0) * D);
-    for (int base = 0; base < total; base += 256 * 4) {
-        f32x4 v[4];
+    const f32x4* xs = reinterpret_cast<const f32x4*>(x + ((long)b * n + srow) * D);
+    f32x4* od = reinterpret_cast<f32x4*>(out + row * D);
+    f32x4 v[4];
+    for (int c0 = 0; c0 < nvec; c0 += 256) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = base + u * 256 + tid;
-            if (e < total) {
-                const int r = e / nvec, c = e - r * nvec;
-                v[u] = xb[(long)src[r] * nvec + c];
-            }
-        }
+        for (int u = 0; u < 4; ++u)
+            if (c0 + u * 64 + lane < nvec) v[u] = xs[c0 + u * 64 + lane];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = base + u * 256 + tid;
-            if (e < total) ob[e] = v[u];
-        }
+        for (int u = 0; u < 4; ++u)
+            if (c0 + u * 64 + lane < nvec) od[c0 + u * 64 + lane] = v[u];
     }
 }
 
+// (A wave-per-row scatter that finds its packed row by a ballot search over the kept ids measured the same, 12.8 vs 13.0 us.)
 // backward: dx[b] = 0 except dx[b,0] (+)= g[b,0], dx[b,1+ids[b,j]] = g[b,1+j].  Every dx row is written exactly
 // once (zeros for dropped tokens), so no atomics and no separate memset.  Inverse map built in LDS per workgroup.
 __global__ __launch_bounds__(256) void scatter_unpack_kernel(const float* __restrict__ g, const long long* __restrict__ ids,
@@ -304,7 +296,8 @@ int d2s_select_topk(const float* probs, int B, int T, int k, long long* kept, lo
 // x [B,n,D] -> out [B,k+1,D]; ids [B,k] int64, stage-relative (0-based over the n-1 non-CLS tokens)
 int d2s_gather_pack_fwd(const float* x, const long long* ids, float* out, int B, int n, int k, int D, hipStream_t stream) {
     if (!x || (!ids && k > 0) || !out || B <= 0 || n <= 0 || k < 0 || k > n - 1 || D <= 0 || (D & 3)) return D2S_ERR_ARG;
-    hipLaunchKernelGGL(gather_pack_kernel, dim3((k + 1 + GROWS - 1) / GROWS, B), dim3(256), 0, stream, x, ids, out, n, k, D);
+    const long rows = (long)B * (k + 1);
+    hipLaunchKernelGGL(gather_pack_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, ids, out, n, k, D, rows);
     return d2s_check_launch();
 }
 
