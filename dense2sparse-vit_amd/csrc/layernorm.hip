@@ -7,6 +7,7 @@
 // Rows may be addressed through a RowMap so that the predictor can read x[:, 1:] of a [B, n, D] buffer in place
 // (dynamic_vit.py:855) and its backward can add into rows 1.. of the gradient buffer.
 #include "d2s_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -95,29 +96,47 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         dw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (long row = r0 + wave; row < r1; row += 4) {
+    // Row loop, software-pipelined for NV <= 4: the loads of the wave's next row (x, dy, the residual gradient, mean, rstd) are
+    // issued before the current row's two wave reductions, so a row costs one memory latency instead of two in series.
+    constexpr bool PIPE = NV <= 4;
+    constexpr bool HOIST = NV <= 8;      // residual-gradient row loaded together with x / dy (registers permitting)
+    f32x4 xv[PIPE ? 2 : 1][NV], gv[PIPE ? 2 : 1][NV], av[PIPE ? 2 : 1][HOIST ? NV : 1];
+    float mr[2][2];
+    auto load_row = [&](long row, int buf) {
         const float* xr = x + map_row(xm, row);
         const float* gr = dy + row * D;
-        const float mean = mean_in[row], rstd = rstd_in[row];
-        f32x4 xh[NV], g[NV];
+        const float* ar = (HOIST && add_src) ? add_src + map_row(dxm, row) : nullptr;
+        mr[buf][0] = mean_in[row];
+        mr[buf][1] = rstd_in[row];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nvec) {
+                xv[buf][i] = *reinterpret_cast<const f32x4*>(xr + c * 4);
+                gv[buf][i] = *reinterpret_cast<const f32x4*>(gr + c * 4);
+                if constexpr (HOIST) av[buf][i] = ar ? *reinterpret_cast<const f32x4*>(ar + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto do_row = [&](long row, int buf) {
+        const float mean = mr[buf][0], rstd = mr[buf][1];
+        f32x4 xh[NV];
         unsigned pos[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
             if (c < nvec) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c * 4);
-                g[i] = *reinterpret_cast<const f32x4*>(gr + c * 4);
                 pos[i] = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    pos[i] |= (xv[j] > 0.f ? 1u : 0u) << j;
-                    xh[i][j] = (xv[j] - mean) * rstd;
-                    const float gw = g[i][j] * wv[i][j];
+                    pos[i] |= (xv[buf][i][j] > 0.f ? 1u : 0u) << j;
+                    xh[i][j] = (xv[buf][i][j] - mean) * rstd;
+                    const float gw = gv[buf][i][j] * wv[i][j];
                     s1 += gw;
                     s2 += gw * xh[i][j];
-                    dw[i][j] += g[i][j] * xh[i][j];
-                    db[i][j] += g[i][j];
+                    dw[i][j] += gv[buf][i][j] * xh[i][j];
+                    db[i][j] += gv[buf][i][j];
                 }
             }
         }
@@ -130,18 +149,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
             if (c < nvec) {
                 f32x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] * wv[i][j] - s1 - xh[i][j] * s2);
+                for (int j = 0; j < 4; ++j) o[j] = rstd * (gv[buf][i][j] * wv[i][j] - s1 - xh[i][j] * s2);
                 if (relu_mask) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = ((pos[i] >> j) & 1u) ? o[j] : 0.f;
                 }
-                if (add_src) {
+                if constexpr (HOIST) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += av[buf][i][j];
+                } else if (add_src) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(add_src + doff + c * 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] += a[j];
                 }
                 *reinterpret_cast<f32x4*>(dx + doff + c * 4) = o;
             }
+        }
+    };
+    if constexpr (PIPE) {
+        long row = r0 + wave;
+        if (row < r1) load_row(row, 0);
+        for (; row < r1; row += 8) {          // two rows per trip so that the buffer index is a compile-time constant
+            if (row + 4 < r1) load_row(row + 4, 1);
+            do_row(row, 0);
+            if (row + 4 < r1) {
+                if (row + 8 < r1) load_row(row + 8, 0);
+                do_row(row + 4, 1);
+            }
+        }
+    } else {
+        for (long row = r0 + wave; row < r1; row += 4) {
+            load_row(row, 0);
+            do_row(row, 0);
         }
     }
     if (!part) return;
@@ -179,18 +218,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 
 // fold the per-block partials: one workgroup per 64 columns of [dweight | dbias]; the 4 waves split the partial
 // index, LDS combines them in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* __restrict__ part, int nblocks, int D,
-                                                          float* __restrict__ dw, float* __restrict__ db, int accumulate) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+// 1024 threads = 16 columns x 64 partial-lanes: each thread adds every 64th partial of its column (few, independent loads), LDS
+// then combines the 64 lane sums of a column in a fixed order.  grid = ceil(2D / 16): 48 workgroups at D = 384 instead of 12.
+constexpr int FOLD_COLS = 16, FOLD_LANES = 64;
+__global__ __launch_bounds__(FOLD_COLS * FOLD_LANES) void ln_bwd_fold_kernel(const float* __restrict__ part, int nblocks, int D,
+                                                                             float* __restrict__ dw, float* __restrict__ db,
+                                                                             int accumulate) {
+    __shared__ float red[FOLD_LANES][FOLD_COLS + 1];
+    const int col = threadIdx.x & (FOLD_COLS - 1), kl = threadIdx.x / FOLD_COLS;
+    const int c = blockIdx.x * FOLD_COLS + col;
     float s = 0.f;
     if (c < 2 * D)
-        for (int k = wave; k < nblocks; k += 4) s += part[(long)k * 2 * D + c];
-    red[wave][lane] = s;
+        for (int k = kl; k < nblocks; k += FOLD_LANES) s += part[(long)k * 2 * D + c];
+    red[kl][col] = s;
     __syncthreads();
-    if (wave == 0 && c < 2 * D) {
-        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (kl == 0 && c < 2 * D) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < FOLD_LANES; ++k) t += red[k][col];
         float* o = c < D ? dw + c : db + (c - D);
         *o = accumulate ? *o + t : t;
     }
@@ -267,8 +312,11 @@ inline int pick_nv(int D) {
     return 16;
 }
 inline int bwd_blocks(long rows) {
+    // one wave walks its rows one after the other (load -> two wave reductions -> store), so the kernel is latency-bound unless
+    // several workgroups share a CU: up to 3 per CU (measured: 256 blocks 48.8 us, 768 blocks see DESIGN.md section 7)
+    static const long cap = [] { const char* e = getenv("D2S_LN_BWD_BLOCKS"); return e ? atol(e) : 768L; }();
     long nb = (rows + 31) / 32;
-    if (nb > 256) nb = 256;
+    if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
@@ -327,7 +375,7 @@ int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, lo
         hipLaunchKernelGGL(ln_bwd_scalar_kernel, grid, block, (size_t)4 * 2 * D * sizeof(float), stream, x, m, dy, w, mean, rstd, dx,
                            add_src, part, rows, D, rpb, relu_mask);
         if (dweight)
-            hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * D + 63) / 64), block, 0, stream, part, nblocks, D, dweight, dbias,
+            hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * D + FOLD_COLS - 1) / FOLD_COLS), dim3(FOLD_COLS * FOLD_LANES), 0, stream, part, nblocks, D, dweight, dbias,
                                accumulate_wb);
         return d2s_check_launch();
     }
@@ -341,7 +389,7 @@ int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, lo
     }
 #undef D2S_LN_BWD
     if (dweight)
-        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * D + 63) / 64), block, 0, stream, part, nblocks, D, dweight, dbias,
+        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * D + FOLD_COLS - 1) / FOLD_COLS), dim3(FOLD_COLS * FOLD_LANES), 0, stream, part, nblocks, D, dweight, dbias,
                            accumulate_wb);
     return d2s_check_launch();
 }
