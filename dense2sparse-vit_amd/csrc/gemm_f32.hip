@@ -63,6 +63,26 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, 
     }
 }
 
+// FAST form (16-byte aligned operand, row extent a multiple of 4 where rows are contiguous, K range a multiple of BK): no guards
+// in the loop.  Rows beyond the extent are CLAMPED to the last valid row / row-chunk (their products only reach C rows or columns
+// that the epilogue never stores), the per-thread element offsets are computed once, the K position moves a wave-uniform base.
+template <int LAY, int BR>
+__device__ __forceinline__ void tile_offsets(long ld, int row0, int rows, int tid, long (&off)[BR / 64]) {
+#pragma unroll
+    for (int i = 0; i < BR / 64; ++i) {
+        const int f = tid + i * 256;
+        if (LAY == 0) off[i] = (long)min(row0 + (f >> 2), rows - 1) * ld + (f & 3) * 4;
+        else off[i] = (long)(f / (BR / 4)) * ld + min(row0 + (f % (BR / 4)) * 4, rows - 4);
+    }
+}
+template <int LAY, int BR>
+__device__ __forceinline__ void load_tile_fast(const float* __restrict__ P, long ld, int k0, const long (&off)[BR / 64],
+                                               f32x4 (&r)[BR / 64]) {
+    const float* base = LAY == 0 ? P + k0 : P + (long)k0 * ld;      // wave-uniform
+#pragma unroll
+    for (int i = 0; i < BR / 64; ++i) r[i] = *reinterpret_cast<const f32x4*>(base + off[i]);
+}
+
 template <int LAY, int BR>
 __device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const f32x4 (&r)[BR / 64]) {
     // S: [BK][BR] floats, element (k,row) at k*BR + (row ^ (((k>>2)&3)<<3))
@@ -82,7 +102,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const
     }
 }
 
-template <int ALAY, int BLAY, int BM, int BN>
+template <int ALAY, int BLAY, int BM, int BN, bool FAST>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;   // 2x2 waves, each MT x NT MFMA tiles of 32x32
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
@@ -140,7 +160,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     for (int i = 0; i < BM / 64; ++i) csum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     f32x4 ra[BM / 64], rb[BN / 64];
-    if (nk > 0) {
+    long offa[BM / 64], offb[BN / 64];
+    if constexpr (FAST) {
+        tile_offsets<ALAY, BM>(p.lda, row0, p.M, tid, offa);
+        tile_offsets<BLAY, BN>(p.ldb, col0, p.N, tid, offb);
+    }
+    if (FAST && nk > 0) {
+        load_tile_fast<ALAY, BM>(p.A, p.lda, kbeg, offa, ra);
+        load_tile_fast<BLAY, BN>(p.B, p.ldb, kbeg, offb, rb);
+        if (ALAY == 1 && do_colsum) {
+#pragma unroll
+            for (int i = 0; i < BM / 64; ++i) csum[i] += ra[i];
+        }
+        store_tile<ALAY, BM>(As, tid, ra);
+        store_tile<BLAY, BN>(Bs, tid, rb);
+    }
+    if (!FAST && nk > 0) {
         load_tile<ALAY, BM>(p.A, p.lda, row0, kbeg, p.M, kend, p.vecA, tid, ra);
         if (ALAY == 1 && do_colsum) {
 #pragma unroll
@@ -154,7 +189,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) {
+        if constexpr (FAST) {   // branch-free prefetch (the last trip re-reads the last slab and discards it)
+            const int kn = kbeg + min(kt + 1, nk - 1) * BK;
+            load_tile_fast<ALAY, BM>(p.A, p.lda, kn, offa, ra);
+            load_tile_fast<BLAY, BN>(p.B, p.ldb, kn, offb, rb);
+        } else if (kt + 1 < nk) {
             load_tile<ALAY, BM>(p.A, p.lda, row0, kbeg + (kt + 1) * BK, p.M, kend, p.vecA, tid, ra);
             load_tile<BLAY, BN>(p.B, p.ldb, col0, kbeg + (kt + 1) * BK, p.N, kend, p.vecB, tid, rb);
         }
@@ -173,6 +212,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+        }
+        if constexpr (FAST) {   // issue order: the K-step's global loads spread between its MFMAs instead of one block ahead of them
+            constexpr int NL = BM / 64 + BN / 64, NM = (BK / 2) * MT * NT;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, NM / NL, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // VMEM read
+            }
         }
         if (kt + 1 < nk) {
             store_tile<ALAY, BM>(As + (cur ^ 1) * BK * BM, tid, ra);
@@ -289,13 +336,18 @@ inline Tile pick_tile(int M, int N) {
     return best;
 }
 
-template <int ALAY, int BLAY>
-inline void launch_gemm(const Tile& t, dim3 grid, hipStream_t stream, const GemmArgs& p) {
+template <int ALAY, int BLAY, bool FAST>
+inline void launch_gemm_f(const Tile& t, dim3 grid, hipStream_t stream, const GemmArgs& p) {
     dim3 block(256);
-    if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 128, 128>), grid, block, 0, stream, p);
-    else if (t.bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 128, 64>), grid, block, 0, stream, p);
-    else if (t.bn == 128) hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 64, 128>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 64, 64>), grid, block, 0, stream, p);
+    if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 128, 128, FAST>), grid, block, 0, stream, p);
+    else if (t.bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 128, 64, FAST>), grid, block, 0, stream, p);
+    else if (t.bn == 128) hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 64, 128, FAST>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 64, 64, FAST>), grid, block, 0, stream, p);
+}
+template <int ALAY, int BLAY>
+inline void launch_gemm(const Tile& t, dim3 grid, hipStream_t stream, const GemmArgs& p, bool fast) {
+    if (fast) launch_gemm_f<ALAY, BLAY, true>(t, grid, stream, p);
+    else launch_gemm_f<ALAY, BLAY, false>(t, grid, stream, p);
 }
 
 }  // namespace
@@ -387,9 +439,13 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
         p.vec_epilogue = (vec_epi_env && epilogue_vec_ok(p) && (p.slab_stride % 4 == 0)) ? 1 : 0;
     }
     dim3 grid(tiles, 1, slices), block(256);
-    if (layout == 0) launch_gemm<0, 0>(tile, grid, stream, p);
-    else if (layout == 1) launch_gemm<0, 1>(tile, grid, stream, p);
-    else launch_gemm<1, 1>(tile, grid, stream, p);
+    // guard-free instantiation: both operands 16-byte loadable, every K slice a whole number of K-steps, and at least one full
+    // 4-row chunk where rows are the contiguous dimension (the clamp needs rows - 4 >= 0)
+    static const int fast_env = [] { const char* e = getenv("D2S_GEMM_FAST"); return e ? atoi(e) : 1; }();
+    const bool fast = fast_env && p.vecA && p.vecB && (K % BK == 0) && (alay == 0 || M >= 4) && (blay == 0 || N >= 4);
+    if (layout == 0) launch_gemm<0, 0>(tile, grid, stream, p, fast);
+    else if (layout == 1) launch_gemm<0, 1>(tile, grid, stream, p, fast);
+    else launch_gemm<1, 1>(tile, grid, stream, p, fast);
     if (slices > 1) {
         const long total = (long)M * N + (colsum_out ? M : 0);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), block, 0, stream,

@@ -92,19 +92,29 @@ __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict
 }
 
 // ---- stage 2: the matrix kernel on ready-made pieces ------------------------------------------------------------------------
-template <int SPLIT, int BK>
-__device__ __forceinline__ void load_pieces(const __bf16* __restrict__ P, int rows, int Kp, int row0, int k0, int tid,
-                                            u32x4 (&r)[SPLIT][BK / 16]) {
-    constexpr int CH = BK / 8;                                  // 16-byte chunks (8 bf16) per K-slab row
+// Piece loads are branch-free: rows beyond the operand's extent are CLAMPED to its last row (their products land in C rows /
+// columns that the epilogue never stores; K padding is real zeros written by the split pass), the per-thread byte offsets are
+// computed once before the loop, and the K position is folded into a wave-uniform base pointer - so a K-step's loads are 2*SPLIT
+// straight-line instructions that the scheduler can place between MFMAs.  (The earlier form had a bounds branch + zero fill per
+// load: 8 exec-mask regions per K-step, issued as one block after the barrier.)
+template <int BK>
+__device__ __forceinline__ void piece_offsets(int rows, int Kp, int row0, int tid, unsigned (&off)[BK / 16]) {
+    constexpr int CH = BK / 8;
 #pragma unroll
     for (int i = 0; i < BK / 16; ++i) {
         const int f = tid + i * 256;
-        const int row = row0 + f / CH, ch = f % CH;
+        const int row = min(row0 + f / CH, rows - 1);
+        off[i] = ((unsigned)row * (unsigned)Kp + (unsigned)(f % CH) * 8u) * (unsigned)sizeof(__bf16);
+    }
+}
+template <int SPLIT, int BK>
+__device__ __forceinline__ void load_pieces(const __bf16* __restrict__ P, long piece_stride, int k0, const unsigned (&off)[BK / 16],
+                                            u32x4 (&r)[SPLIT][BK / 16]) {
 #pragma unroll
-        for (int s = 0; s < SPLIT; ++s) {
-            if (row < rows) r[s][i] = *reinterpret_cast<const u32x4*>(P + ((long)s * rows + row) * Kp + k0 + ch * 8);
-            else r[s][i] = u32x4{0u, 0u, 0u, 0u};
-        }
+    for (int s = 0; s < SPLIT; ++s) {
+        const char* base = reinterpret_cast<const char*>(P + s * piece_stride + k0);      // wave-uniform
+#pragma unroll
+        for (int i = 0; i < BK / 16; ++i) r[s][i] = *reinterpret_cast<const u32x4*>(base + off[i]);
     }
 }
 template <int SPLIT, int BK>
@@ -174,12 +184,15 @@ __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, co
 struct PieceArgs { const __bf16* Ap; const __bf16* Bp; int Kp; };
 
 #ifdef D2S_STAMPS   // diagnostic build only: per-workgroup {entry, loop begin, loop end, exit} in 100 MHz ticks + cycles of the loop
-__device__ unsigned long long g_stamps[8 * 32768];
-#define STAMP(i) if (tid == 0 && blockIdx.x < 32768) g_stamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime()
-#define STAMPC(i) if (tid == 0 && blockIdx.x < 32768) g_stamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime()
+__device__ unsigned long long g_stamps[16 * 32768];
+#define STAMP(i) if (tid == 0 && blockIdx.x < 32768) g_stamps[16 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime()
+#define STAMPC(i) if (tid == 0 && blockIdx.x < 32768) g_stamps[16 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime()
+// phase stamp inside K-step 5 (cycles), fenced so that the scheduler keeps it between the phases it separates
+#define STAMPK(i) do { __builtin_amdgcn_sched_barrier(0); if (kt == 5) { STAMPC(i); } __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define STAMP(i)
 #define STAMPC(i)
+#define STAMPK(i)
 #endif
 
 template <int SPLIT, int BK, bool AF32>
@@ -213,21 +226,31 @@ __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, Piec
 
     u32x4 ra[AF32 ? 1 : SPLIT][BK / 16], rb[SPLIT][BK / 16];
     f32x4 fa[BK / 16][2];
+    unsigned offa[BK / 16], offb[BK / 16];
+    piece_offsets<BK>(p.M, q.Kp, row0, tid, offa);
+    piece_offsets<BK>(p.N, q.Kp, col0, tid, offb);
+    const long strideA = (long)p.M * q.Kp, strideB = (long)p.N * q.Kp;
     if constexpr (AF32) load_a_f32<BK>(p.A, p.lda, p.M, p.K, row0, 0, tid, fa);
-    else load_pieces<SPLIT, BK>(q.Ap, p.M, q.Kp, row0, 0, tid, ra);
-    load_pieces<SPLIT, BK>(q.Bp, p.N, q.Kp, col0, 0, tid, rb);
+    else load_pieces<SPLIT, BK>(q.Ap, strideA, 0, offa, ra);
+    load_pieces<SPLIT, BK>(q.Bp, strideB, 0, offb, rb);
 
     STAMP(1); STAMPC(4);
     for (int kt = 0; kt < nk; ++kt) {
+        STAMPK(8);
         if constexpr (AF32) store_a_split<SPLIT, BK>(As, tid, fa);
         else store_pieces<SPLIT, BK>(As, tid, ra);
         store_pieces<SPLIT, BK>(Bs, tid, rb);
+        STAMPK(9);
         __syncthreads();
-        if (kt + 1 < nk) {
-            if constexpr (AF32) load_a_f32<BK>(p.A, p.lda, p.M, p.K, row0, (kt + 1) * SBK, tid, fa);
-            else load_pieces<SPLIT, BK>(q.Ap, p.M, q.Kp, row0, (kt + 1) * SBK, tid, ra);
-            load_pieces<SPLIT, BK>(q.Bp, p.N, q.Kp, col0, (kt + 1) * SBK, tid, rb);
+        STAMPK(10);
+        {   // prefetch of the next K-slab; on the last trip it re-reads the last slab (harmless) so that the body has no branch and
+            // the loads can be scheduled between the MFMAs below
+            const int kn = min(kt + 1, nk - 1) * SBK;
+            if constexpr (AF32) load_a_f32<BK>(p.A, p.lda, p.M, p.K, row0, kn, tid, fa);
+            else load_pieces<SPLIT, BK>(q.Ap, strideA, kn, offa, ra);
+            load_pieces<SPLIT, BK>(q.Bp, strideB, kn, offb, rb);
         }
+        STAMPK(11);
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 a[SPLIT][2], b[SPLIT][2];
@@ -253,7 +276,20 @@ __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, Piec
                     acc[mt][nt] = mfma_bf16(a[0][mt], b[0][nt], c);
                 }
         }
+#ifndef D2S_STAMPS
+        if constexpr (!AF32) {   // issue order: one global load after every NM / NL MFMAs (a block of loads ahead of the MFMAs stalls
+                                 // the wave's in-order issue on the CU's 64 B/clk vector-memory path - measured 2100 of 5400 cycles)
+            constexpr int NL = 2 * SPLIT * (BK / 16), NM = (BK / 16) * 4 * (SPLIT == 3 ? 6 : 1);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, NM / NL, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // VMEM read
+            }
+        }
+#endif
+        STAMPK(12);
         __syncthreads();
+        STAMPK(13);
     }
 
     STAMP(2); STAMPC(5);
@@ -295,6 +331,7 @@ size_t split_workspace_bytes(int split, int M, int N, int K) {
 int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     const int Kp = ((p.K + 31) / 32) * 32;
     if (!workspace || workspace_bytes < split_workspace_bytes(split, p.M, p.N, p.K)) return D2S_ERR_WORKSPACE;
+    if ((long)p.M * Kp * 2 >= (1L << 32) || (long)p.N * Kp * 2 >= (1L << 32)) return D2S_ERR_ARG;   // per-thread byte offsets are 32-bit
     __bf16* Ap = static_cast<__bf16*>(workspace);
     __bf16* Bp = reinterpret_cast<__bf16*>(static_cast<unsigned char*>(workspace) + align256((size_t)split * p.M * Kp * sizeof(__bf16)));
     const long ea = (long)p.M * (Kp / 4), eb = (long)p.N * (Kp / 4);
@@ -339,7 +376,7 @@ int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace,
 
 #ifdef D2S_STAMPS
 extern "C" int d2s_debug_read_stamps(unsigned long long* host_out, int n_wg) {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), (size_t)n_wg * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), (size_t)n_wg * 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
 
