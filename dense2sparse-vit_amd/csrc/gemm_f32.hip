@@ -199,26 +199,45 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         }
         const float* Ac = As + cur * BK * BM;
         const float* Bc = Bs + cur * BK * BN;
+        // fragments are read one K-pair ahead of the MFMAs that consume them (two register sets), so the LDS round trip of pair
+        // s + 1 runs under the four MFMAs of pair s
+        float a[2][MT], b[2][NT];
+        auto read_frags = [&](int sp, float (&af)[MT], float (&bf)[NT]) {
+            const int k = 2 * sp + half;
+            const int sw = ((k >> 2) & 3) << 3;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = Ac[k * BM + ((wm * WM + i * 32 + l31) ^ sw)];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = Bc[k * BN + ((wn * WN + j * 32 + l31) ^ sw)];
+        };
+        read_frags(0, a[0], b[0]);
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
-            const int k = 2 * s + half;
-            const int sw = ((k >> 2) & 3) << 3;
-            float a[MT], b[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = Ac[k * BM + ((wm * WM + i * 32 + l31) ^ sw)];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = Bc[k * BN + ((wn * WN + j * 32 + l31) ^ sw)];
+            if (s + 1 < BK / 2) read_frags(s + 1, a[(s + 1) & 1], b[(s + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(a[s & 1][i], b[s & 1][j], acc[i][j]);
         }
-        if constexpr (FAST) {   // issue order: the K-step's global loads spread between its MFMAs instead of one block ahead of them
-            constexpr int NL = BM / 64 + BN / 64, NM = (BK / 2) * MT * NT;
+        if constexpr (FAST) {
+            // Pinned issue order for the K-step (measured per tile shape, tools/gemm_bench.py): the global loads are spread between
+            // the MFMA groups instead of one block ahead of them; for the narrower tiles the fragment reads of pair s + 1 are also
+            // pinned ahead of the MFMAs of pair s (+4-6 % there, -1.5 % on 128x128 where the compiler's own placement is better).
+            constexpr int NL = BM / 64 + BN / 64, NP = BK / 2, DSR = (MT + 1) / 2 + (NT + 1) / 2;
+            if constexpr (BM == 128 && BN == 128) {
 #pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, NM / NL, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // VMEM read
+                for (int i = 0; i < NL; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, NP * MT * NT / NL, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                   // VMEM read
+                }
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x100, DSR, 0);                     // DS read: pair 0
+#pragma unroll
+                for (int sp = 0; sp < NP; ++sp) {
+                    if (sp + 1 < NP) __builtin_amdgcn_sched_group_barrier(0x100, DSR, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);             // MFMA
+                    if (sp % (NP / NL) == NP / NL - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                }
             }
         }
         if (kt + 1 < nk) {
