@@ -376,6 +376,28 @@ size_t split_workspace_bytes(int split, int M, int N, int K);
 int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace, size_t workspace_bytes, hipStream_t stream);
 }
 static int g_gemm_mode = 0;
+// Workgroups the wgrad launch aims for (tiles x K slices, rounded down): exactly 2 per CU.  Measured on the model's shapes
+// (tools/gemm_bench.py, D2S_SPLITK_TARGET sweep): 512 beats 768 / 1024 by 4-15 % (fewer, longer K slices: less slab traffic for the
+// ordered combine), and any count that is not a multiple of the CU count loses 10-40 % to imbalance.
+static int splitk_target() {
+    static const int t = [] {
+        const char* e = getenv("D2S_SPLITK_TARGET");
+        if (e) return atoi(e);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        return 2 * cus;
+    }();
+    return t;
+}
+static int splitk_slices(int tiles, int K) {
+    const int target = splitk_target();
+    int slices = target >= 100000 ? (target - 100000 + tiles - 1) / tiles : target / tiles;   // >= 100000: round up, else round down
+    const int max_slices = (K + 255) / 256;
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    return slices;
+}
 
 extern "C" {
 
@@ -389,9 +411,7 @@ size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K) {
     if (layout != 2 && g_gemm_mode != 0) return split_workspace_bytes(g_gemm_mode == 1 ? 3 : 1, M, N, K);   // bf16 piece matrices
     if (layout != 2) return 0;
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    int slices = (1024 + tiles - 1) / tiles;
-    const int max_slices = (K + 255) / 256;
-    if (slices > max_slices) slices = max_slices;
+    const int slices = splitk_slices(tiles, K);
     if (slices <= 1) return 0;
     return ((size_t)slices * M * N + (size_t)slices * M) * sizeof(float);   // C slabs + fused bias-gradient slabs
 }
@@ -430,10 +450,7 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
     const int tiles = ((M + tile.bm - 1) / tile.bm) * ((N + tile.bn - 1) / tile.bn);
     int slices = 1;
     if (layout == 2) {
-        slices = (1024 + tiles - 1) / tiles;
-        const int max_slices = (K + 255) / 256;
-        if (slices > max_slices) slices = max_slices;
-        if (slices < 1) slices = 1;
+        slices = splitk_slices(tiles, K);
     }
     int kper = (K + slices - 1) / slices;
     kper = ((kper + BK - 1) / BK) * BK;
