@@ -77,7 +77,7 @@ __device__ __forceinline__ void mma_reg_lds(const f32x16& p, const float* __rest
 // ---------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                        float* __restrict__ lse, float* __restrict__ cls_row, int n, int H,
                                                        float scale) {
     __shared__ __attribute__((aligned(16))) float Ks[32 * PITCH];
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 // ---------------------------------------------------------------------------------------------------------
 // backward, dQ: one wave per 32 queries, loops over key tiles (same orientation as forward)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           float* __restrict__ dqkv, int n, int H, float scale) {
     __shared__ __attribute__((aligned(16))) float Ks[32 * PITCH];
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------------
 // backward, dK / dV: one wave per 32 keys, loops over query tiles (natural orientation S = Q K^T)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            float* __restrict__ dqkv, int n, int H, float scale) {
     __shared__ __attribute__((aligned(16))) float Qs[32 * PITCH];

@@ -1,0 +1,23 @@
+"""Fused attention forward / backward per-launch time at the model's shapes (GPU box only): B=128, H=6, dh=64."""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "dense2sparse-vit_amd"))
+import torch
+from d2s import ops
+dev = torch.device("cuda:0")
+B, H = 128, 6
+for n in (197, 99):
+    qkv = torch.randn(B * n, 3 * H * 64, device=dev)
+    dout = torch.randn(B * n, H * 64, device=dev)
+    out, lse, _ = ops.attn_fwd(qkv, B, n, H, 0.125)
+    def fwd(): ops.attn_fwd(qkv, B, n, H, 0.125)
+    def bwd(): ops.attn_bwd(qkv, out, dout, lse, B, n, H, 0.125)
+    for name, fn, fl in (("fwd", fwd, 4.0 * n * n * 64 * B * H), ("bwd", bwd, 10.0 * n * n * 64 * B * H)):
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(30): fn()
+        e.record(); torch.cuda.synchronize()
+        us = s.elapsed_time(e) * 1000 / 30
+        print(f"n {n:4d} {name} {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s (algorithmic, unpadded)")
