@@ -182,11 +182,18 @@ def cpu_baseline(keep, batch=32, warm=2, steps=10):
                 sample=f"{steps} full train steps of the CPU oracle at batch {batch} (same model/config, fp32), after {warm} warm-up; {dt:.1f} s")
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, KB -> bytes), or None."""
+PMC_FILE = "r01_g_pmc_traffic.json"
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, KB -> bytes): the launch-weighted
+    mean over every kernel whose name starts with `kernel_prefix` (the tile-shape variants of one GEMM layout), or None."""
     try:
-        with open(os.path.join(REPO, "profiles", "r01_c_pmc_traffic.json")) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+        with open(os.path.join(REPO, "profiles", PMC_FILE)) as f:
+            ks = json.load(f)["kernels"]
+        sel = [v for k, v in ks.items() if k.startswith(kernel_prefix)]
+        n = sum(v["launches"] for v in sel)
+        return int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n) if n else None
     except Exception:
         return None
 
@@ -326,8 +333,8 @@ def main():
             ach = gemms[dom]["work"] / (gemms[dom]["ms"] * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "kernel": f"gemm_f32_kernel<{dom[1]}> (v_mfma_f32_32x32x2_f32)",
                                 "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("gemm_f32_kernel<0, 0, 128, 128>") if dom[1] == "NT" else None,
-                                "traffic_note": "HBM bytes per launch of the 128x128 NT variant from the committed PMC passes (profiles/r01_c_pmc_traffic.json); not collected live",
+                                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic({"NT": "gemm_f32_kernel<0, 0,", "NN": "gemm_f32_kernel<0, 1,", "TN": "gemm_f32_kernel<1, 1,"}[dom[1]]),
+                                "traffic_note": f"HBM bytes per launch, launch-weighted mean over this layout's tile-shape variants, from the committed PMC passes (profiles/{PMC_FILE}); not collected live",
                                 "avg_launch_us": round(1000.0 * gemms[dom]["ms"] / gemms[dom]["launches"], 2),
                                 "launches_per_step": gemms[dom]["launches"] / args.steps,
                                 "all_gemm_layouts": {k[1]: {"TFLOP/s": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),
