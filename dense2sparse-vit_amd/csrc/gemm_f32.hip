@@ -103,7 +103,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const
 }
 
 template <int ALAY, int BLAY, int BM, int BN, bool FAST>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 1) void gemm_f32_kernel(GemmArgs p) {
     constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;   // 2x2 waves, each MT x NT MFMA tiles of 32x32
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
     float* As = smem;                 // [2][BK][BM]
