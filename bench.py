@@ -44,9 +44,26 @@ def parse():
     ap.add_argument("--gemm-mode", choices=["exact", "split", "bf16"], default="exact",
                     help="exact: v_mfma_f32_32x32x2_f32 (default, fp32 fma chain); split: bf16x3 on the bf16 matrix cores, fp32-class "
                          "accuracy; bf16: bf16 operands, fp32 accumulate (forward/dgrad GEMMs; wgrad stays exact)")
+    ap.add_argument("--config", choices=["headline", "c2", "c3", "c4", "c5"], default="headline",
+                    help="BASELINE.json config matrix: headline = DeiT-S keep 0.5 B=128 (the metric's config, default); c2 = DeiT-S keep 0.7 "
+                         "B=128; c3 = DeiT-S 3-stage 0.7/0.5/0.3 B=32/GPU; c4 = T2T-ViT-14 keep 0.5 B=64/GPU; c5 = DeiT-B 384^2 keep 0.3 "
+                         "bf16 GEMM operands B=64/GPU.  Non-headline presets skip the CPU baseline and set batch / keep / gemm mode.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events (pure step timing)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    a.locs, a.keeps, a.arch, a.img = [3], [a.keep], "deit_small", 224
+    if a.config == "c2":
+        a.keeps = [0.7]
+    elif a.config == "c3":
+        a.locs, a.keeps, a.batch = [3, 6, 9], [0.7, 0.5, 0.3], 32
+    elif a.config == "c4":
+        a.arch, a.keeps, a.batch = "t2t_vit_14", [0.5], 64
+    elif a.config == "c5":
+        a.arch, a.img, a.keeps, a.batch, a.gemm_mode = "deit_base", 384, [0.3], 64, "bf16"
+    if a.config != "headline":
+        a.no_cpu_baseline = True
+        a.keep = a.keeps[0]
+    return a
 
 
 class KernelTimer:
@@ -145,11 +162,21 @@ def hbm_copy_gbs(device, mbytes=1024, reps=10):
     return round(2.0 * a.numel() * reps / (s.elapsed_time(e) * 1e-3) / 1e9, 1)
 
 
-def build(device, keep, seed=0):
+def build(device, keep, seed=0, arch="deit_small", locs=(3,), keeps=None, img=224):
     import vit_models
     torch.manual_seed(seed)
-    student = vit_models.dynamic_vit_small_patch16_224_student([3], [keep], topk_selection=True, predictor_loss_type="kl_div")
-    teacher = vit_models.dynamic_vit_small_patch16_224_teacher()
+    keeps = list(keeps) if keeps else [keep]
+    if arch == "t2t_vit_14":
+        student = vit_models.t2t_vit_14_student(list(locs), keeps)
+        teacher = vit_models.t2t_vit_14_teacher()
+    elif arch == "deit_base":
+        geom = dict(img_size=img, patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True)
+        student = vit_models.VisionTransformerDiffPruning(pruning_loc=list(locs), token_ratio=keeps, distill=True, topk_selection=True,
+                                                          predictor_loss_type="kl_div", **geom)
+        teacher = vit_models.VisionTransformerTeacher(**geom)
+    else:
+        student = vit_models.dynamic_vit_small_patch16_224_student(list(locs), keeps, topk_selection=True, predictor_loss_type="kl_div")
+        teacher = vit_models.dynamic_vit_small_patch16_224_teacher()
     return student.to(device), teacher.to(device)
 
 
@@ -271,8 +298,8 @@ def main():
     timer = KernelTimer()
     timer.wrap(ops)
 
-    student, teacher = build(device, args.keep)
-    targs = types.SimpleNamespace(keep_ratios=[args.keep], mask_loss_type="kl_div", mixup=0.0, patch_score_threshold=None, step=0)
+    student, teacher = build(device, args.keep, arch=args.arch, locs=args.locs, keeps=args.keeps, img=args.img)
+    targs = types.SimpleNamespace(keep_ratios=list(args.keeps), mask_loss_type="kl_div", mixup=0.0, patch_score_threshold=None, step=0)
     ts = TrainStep(student, teacher, targs, lr=5e-4, min_lr=1e-5, weight_decay=0.05, epochs=25, warmup_steps=0,
                    distributed=distributed)
     if distributed:
@@ -280,7 +307,7 @@ def main():
         dist.broadcast(ts.arena.params, src=0)
 
     g = torch.Generator(device=device).manual_seed(1234 + rank)
-    images = torch.randn((args.batch, 3, 224, 224), device=device, generator=g)
+    images = torch.randn((args.batch, 3, args.img, args.img), device=device, generator=g)
     labels = torch.randint(0, 1000, (args.batch,), device=device, generator=g)
 
     log(f"models built on {device}; {args.warmup} warm-up steps")
@@ -316,11 +343,15 @@ def main():
         n_gpus = world
         imgs = args.batch * n_gpus * args.steps
         line = {
-            "metric": "training images/s, DeiT-S 224 keep_ratio=0.5 (dense-to-sparse ViT train step, teacher fwd + student fwd/bwd + AdamW)",
+            "metric": "training images/s, DeiT-S 224 keep_ratio=0.5 (dense-to-sparse ViT train step, teacher fwd + student fwd/bwd + AdamW)"
+                      if args.config == "headline" and args.keep == 0.5 else
+                      f"training images/s, BASELINE config {args.config} (NOT the headline metric): {args.arch} {args.img}^2 keep {args.keeps}",
             "value": round(imgs / elapsed, 2), "unit": "images/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"exact": "f32", "split": "f32 (bf16x3-split MFMA, fp32-class accuracy)", "bf16": "bf16 GEMM operands, f32 accumulate/elsewhere"}[args.gemm_mode], "data": "synthetic (N(0,1) images, uniform labels, random-init weights)",
-            "config": {"workload": f"DeiT-Small 224x224 patch16, 1-stage prune keep_ratio={args.keep} @ block 3 (196->{int(196 * args.keep)} tokens), "
+            "config": {"workload": (f"DeiT-Small 224x224 patch16, 1-stage prune keep_ratio={args.keep} @ block 3 (196->{int(196 * args.keep)} tokens), "
+                                    f"large LN predictor, kl_div mask loss, per-GPU batch {args.batch}") if args.config in ("headline", "c2") else
+                                   f"BASELINE config {args.config}: {args.arch} {args.img}x{args.img}, prune @ {args.locs} keep {args.keeps}, "
                                    f"large LN predictor, kl_div mask loss, per-GPU batch {args.batch}",
                        "global_batch": args.batch * n_gpus, "parallelism": f"dp{n_gpus}", "final_loss": round(loss, 5)},
         }
@@ -355,7 +386,7 @@ def main():
                               "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                               "bytes_per_launch": ga["work"] / ga["launches"], "avg_launch_us": round(1000.0 * ga["ms"] / ga["launches"], 2),
                               "traffic": pmc_traffic("gather_pack_kernel"), "at_batch_2048": gather_large(device),
-                              "back_to_back_hbm_cold": gather_back_to_back(device, args.batch, k=int(196 * args.keep))}
+                              "back_to_back_hbm_cold": gather_back_to_back(device, args.batch, k=int(196 * args.keep)) if args.config == "headline" else None}
         line["hbm_copy_GBps_measured"] = hbm_copy_gbs(device)
         if distributed:
             c = ts.reducer.comm_summary(args.steps)
