@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--keep", type=float, default=0.5)
     ap.add_argument("--gemm-mode", choices=["exact", "split", "bf16"], default="exact",
                     help="exact: v_mfma_f32_32x32x2_f32 (default, fp32 fma chain); split: bf16x3 on the bf16 matrix cores, fp32-class "
-                         "accuracy; bf16: bf16 operands, fp32 accumulate (forward/dgrad GEMMs; wgrad stays exact)")
+                         "accuracy; bf16: bf16 operands, fp32 accumulate (all three GEMM layouts; bias gradients, LayerNorm, softmax, selection, losses, AdamW stay fp32)")
     ap.add_argument("--config", choices=["headline", "c2", "c3", "c4", "c5"], default="headline",
                     help="BASELINE.json config matrix: headline = DeiT-S keep 0.5 B=128 (the metric's config, default); c2 = DeiT-S keep 0.7 "
                          "B=128; c3 = DeiT-S 3-stage 0.7/0.5/0.3 B=32/GPU; c4 = T2T-ViT-14 keep 0.5 B=64/GPU; c5 = DeiT-B 384^2 keep 0.3 "

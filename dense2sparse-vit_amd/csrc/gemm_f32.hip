@@ -376,6 +376,8 @@ inline void launch_gemm(const Tile& t, dim3 grid, hipStream_t stream, const Gemm
 namespace d2s_gemm {
 size_t split_workspace_bytes(int split, int M, int N, int K);
 int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace, size_t workspace_bytes, hipStream_t stream);
+size_t split_tn_pieces_bytes(int split, int M, int N, int K);
+int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_ws, hipStream_t stream);
 }
 static int g_gemm_mode = 0;
 // Workgroups the wgrad launch aims for (tiles x K slices, rounded down): exactly 2 per CU.  Measured on the model's shapes
@@ -392,6 +394,15 @@ static int splitk_target() {
     }();
     return t;
 }
+static inline size_t ws_align(size_t x) { return (x + 255) & ~(size_t)255; }
+// mode 2 only: run the weight gradient on the bf16 matrix cores too (D2S_BF16_WGRAD=0 keeps it on the exact fp32 kernel)
+static bool bf16_wgrad() {
+    static const int on = [] { const char* e = getenv("D2S_BF16_WGRAD"); return e ? atoi(e) : 1; }();
+    return g_gemm_mode == 2 && on;
+}
+extern "C" size_t d2s_colsum_workspace_bytes(int M, int N);
+extern "C" int d2s_colsum_f32(const float* X, long ldx, int M, int N, float* out, int accumulate, void* workspace,
+                              size_t workspace_bytes, hipStream_t stream);
 static int splitk_slices(int tiles, int K) {
     const int target = splitk_target();
     int slices = target >= 100000 ? (target - 100000 + tiles - 1) / tiles : target / tiles;   // >= 100000: round up, else round down
@@ -405,7 +416,8 @@ extern "C" {
 
 // Workspace needed by d2s_gemm_f32 for a given problem (only the TN / wgrad layout splits K).
 // 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  1: bf16x3 split on the bf16 matrix cores, fp32-class accuracy (gemm_split.hip).
-// 2: bf16 operands, fp32 accumulation.  Applies to the NT and NN layouts; wgrad (TN) always runs the exact kernel.
+// 2: bf16 operands, fp32 accumulation.  Modes 1 and 2 apply to the NT and NN layouts; in mode 2 wgrad (TN) also runs on the bf16
+// matrix cores (transposing split + K-sliced pieces kernel + the same ordered slab combine), in mode 1 it stays on the exact kernel.
 void d2s_set_gemm_mode(int mode) { g_gemm_mode = (mode == 1 || mode == 2) ? mode : 0; }
 int d2s_get_gemm_mode(void) { return g_gemm_mode; }
 
@@ -414,8 +426,10 @@ size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K) {
     if (layout != 2) return 0;
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     const int slices = splitk_slices(tiles, K);
-    if (slices <= 1) return 0;
-    return ((size_t)slices * M * N + (size_t)slices * M) * sizeof(float);   // C slabs + fused bias-gradient slabs
+    size_t bytes = slices <= 1 ? 0 : ((size_t)slices * M * N + (size_t)slices * M) * sizeof(float);   // C slabs + fused bias-gradient slabs
+    if (bf16_wgrad())   // + bf16 pieces of both operands + scratch of the separate bias-gradient pass (see gemm_impl)
+        bytes = ws_align(((size_t)(slices + 1) * M * N) * sizeof(float)) + ws_align(split_tn_pieces_bytes(1, M, N, K)) + d2s_colsum_workspace_bytes(K, M);
+    return bytes;
 }
 
 // layout 0 = NT (A[M,K], B[N,K]); 1 = NN (A[M,K], B[K,N]); 2 = TN (A[K,M], B[K,N]).
@@ -447,6 +461,37 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
         p.k_per_slice = K;
         p.slab_stride = 0;
         return launch_split_gemm(p, layout == 1 ? 1 : 0, g_gemm_mode == 1 ? 3 : 1, workspace, workspace_bytes, stream);
+    }
+    if (layout == 2 && bf16_wgrad()) {
+        // wgrad in bf16 mode: transposing split of dy and x into K-contiguous bf16 pieces, K-sliced pieces kernel into fp32 slabs,
+        // the same ordered slab combine as the exact path; the bias gradient is a separate exact fp32 column-sum pass over dy.
+        const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+        int slices = splitk_slices(tiles, K);
+        const int Kp = ((K + 31) / 32) * 32;
+        int kper = (((Kp + slices - 1) / slices + 31) / 32) * 32;
+        slices = (Kp + kper - 1) / kper;
+        const size_t slab_bytes = ws_align(((size_t)(slices + 1) * M * N) * sizeof(float));
+        const size_t piece_bytes = ws_align(split_tn_pieces_bytes(1, M, N, K));
+        const size_t cs_bytes = d2s_colsum_workspace_bytes(K, M);
+        if (!workspace || workspace_bytes < slab_bytes + piece_bytes + cs_bytes) return D2S_ERR_WORKSPACE;
+        unsigned char* wsb = static_cast<unsigned char*>(workspace);
+        p.k_per_slice = kper;
+        p.epi = EPI_NONE;
+        p.C = reinterpret_cast<float*>(wsb);
+        p.ldc = N;
+        p.slab_stride = (long)M * N;
+        p.remap_rows_per_img = 0;
+        int rc = launch_split_gemm_tn(p, 1, slices, wsb + slab_bytes, stream);
+        if (rc != D2S_OK) return rc;
+        const long total = (long)M * N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<const float*>(wsb), C, ldc, M, N, slices, (long)M * N, accumulate,
+                           static_cast<const float*>(nullptr), static_cast<float*>(nullptr));
+        if (colsum_out) {
+            rc = d2s_colsum_f32(A, lda, K, M, colsum_out, accumulate, wsb + slab_bytes + piece_bytes, cs_bytes, stream);
+            if (rc != D2S_OK) return rc;
+        }
+        return d2s_check_launch();
     }
     Tile tile = layout == 2 ? Tile{128, 128, 1.f} : pick_tile(M, N);
     const int tiles = ((M + tile.bm - 1) / tile.bm) * ((N + tile.bn - 1) / tile.bn);

@@ -69,25 +69,51 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     }
 }
 
-// ---- stage 1b: source [K][R] (ld, row index contiguous) -> pieces [SPLIT][R][Kp], 32x32 transposes through LDS ------------------
+// ---- stage 1b: source [K][R] (ld, row index contiguous) -> pieces [SPLIT][R][Kp]: 64 x 64 transposes through LDS ----------------
+// Loads: 16 bytes along r (4 rows of one k).  Stores: 16 bytes along k (8 bf16 of one row); a wave covers 8 rows x 128 contiguous
+// bytes per instruction.  LDS image [64 k][65]: the column walk of the store phase is at worst 2-way conflicted.
 template <int SPLIT>
 __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict__ src, long ld, __bf16* __restrict__ dst, int R, int K,
-                                                         int Kp) {
-    __shared__ float t[32][33];
-    const int r0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int j = ty; j < 32; j += 8)          // read: k = k0 + j, r = r0 + tx (coalesced along r)
-        t[j][tx] = (k0 + j < K && r0 + tx < R) ? src[(long)(k0 + j) * ld + r0 + tx] : 0.f;
+                                                         int Kp, int vec) {
+    __shared__ float t[64][65];
+    const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                 // 64 k x 16 float4
+        const int f = tid + i * 256, k = f >> 4, r4 = (f & 15) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k0 + k < K) {
+            const float* p = src + (long)(k0 + k) * ld + r0 + r4;
+            if (vec && r0 + r4 + 3 < R) {
+                v = *reinterpret_cast<const f32x4*>(p);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (r0 + r4 + j < R) v[j] = p[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[k][r4 + j] = v[j];
+    }
     __syncthreads();
-    for (int j = ty; j < 32; j += 8) {        // write: r = r0 + j, k = k0 + tx (coalesced along k)
-        if (r0 + j >= R) continue;
-        const float a = t[tx][j];
-        __bf16 h, m = (__bf16)0.f, l = (__bf16)0.f;
-        if constexpr (SPLIT == 3) split3(a, h, m, l);
-        else h = (__bf16)a;
-        __bf16* d = dst + (long)(r0 + j) * Kp + k0 + tx;
-        *d = h;
-        if constexpr (SPLIT == 3) { d[(long)R * Kp] = m; d[2L * R * Kp] = l; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                 // 64 rows x 8 chunks of 8 k
+        const int f = tid + i * 256, c = f & 7, r = f >> 3;
+        if (r0 + r >= R || k0 + c * 8 >= Kp) continue;
+        bf16x8 h, m, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = t[c * 8 + j][r];
+            __bf16 hh, mm = (__bf16)0.f, ll = (__bf16)0.f;
+            if constexpr (SPLIT == 3) split3(a, hh, mm, ll);
+            else hh = (__bf16)a;
+            h[j] = hh; m[j] = mm; l[j] = ll;
+        }
+        __bf16* d = dst + (long)(r0 + r) * Kp + k0 + c * 8;
+        *reinterpret_cast<bf16x8*>(d) = h;
+        if constexpr (SPLIT == 3) {
+            *reinterpret_cast<bf16x8*>(d + (long)R * Kp) = m;
+            *reinterpret_cast<bf16x8*>(d + 2L * R * Kp) = l;
+        }
     }
 }
 
@@ -214,7 +240,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, Piec
         bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
     }
     const int row0 = (bid / nbn) * SBM, col0 = (bid % nbn) * SBN;
-    const int nk = q.Kp / SBK;
+    // K slices (wgrad): slice z covers k in [z * k_per_slice, ...) and writes its own C slab; one slice covers all of Kp otherwise
+    const int kbeg = blockIdx.z * p.k_per_slice;
+    const int nk = (min(q.Kp, kbeg + p.k_per_slice) - kbeg) / SBK;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -230,9 +258,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, Piec
     piece_offsets<BK>(p.M, q.Kp, row0, tid, offa);
     piece_offsets<BK>(p.N, q.Kp, col0, tid, offb);
     const long strideA = (long)p.M * q.Kp, strideB = (long)p.N * q.Kp;
-    if constexpr (AF32) load_a_f32<BK>(p.A, p.lda, p.M, p.K, row0, 0, tid, fa);
-    else load_pieces<SPLIT, BK>(q.Ap, strideA, 0, offa, ra);
-    load_pieces<SPLIT, BK>(q.Bp, strideB, 0, offb, rb);
+    if constexpr (AF32) load_a_f32<BK>(p.A, p.lda, p.M, p.K, row0, kbeg, tid, fa);
+    else load_pieces<SPLIT, BK>(q.Ap, strideA, kbeg, offa, ra);
+    load_pieces<SPLIT, BK>(q.Bp, strideB, kbeg, offb, rb);
 
     STAMP(1); STAMPC(4);
     for (int kt = 0; kt < nk; ++kt) {
@@ -245,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, Piec
         STAMPK(10);
         {   // prefetch of the next K-slab; on the last trip it re-reads the last slab (harmless) so that the body has no branch and
             // the loads can be scheduled between the MFMAs below
-            const int kn = min(kt + 1, nk - 1) * SBK;
+            const int kn = kbeg + min(kt + 1, nk - 1) * SBK;
             if constexpr (AF32) load_a_f32<BK>(p.A, p.lda, p.M, p.K, row0, kn, tid, fa);
             else load_pieces<SPLIT, BK>(q.Ap, strideA, kn, offa, ra);
             load_pieces<SPLIT, BK>(q.Bp, strideB, kn, offb, rb);
@@ -293,21 +321,22 @@ __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, Piec
     }
 
     STAMP(2); STAMPC(5);
+    float* Cb = p.C + (long)blockIdx.z * p.slab_stride;
     if (p.vec_epilogue) {   // LDS is free after the loop's final barrier; each wave uses its own staging buffer
         float* stage = reinterpret_cast<float*>(smem_raw) + wave * epi_stage_floats(2);
-        store_tile_dispatch_lds<2, 2>(p.epi, p, p.C, acc, row0 + wm * 64, col0 + wn * 64, lane, stage);
+        store_tile_dispatch_lds<2, 2>(p.epi, p, Cb, acc, row0 + wm * 64, col0 + wn * 64, lane, stage);
     } else {
     const int mbase = row0 + wm * 64, nbase = col0 + wn * 64 + l31;
     switch (p.epi) {
-        case EPI_BIAS: store_tile_out<EPI_BIAS, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
-        case EPI_BIAS_RELU: store_tile_out<EPI_BIAS_RELU, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
-        case EPI_BIAS_GELU: store_tile_out<EPI_BIAS_GELU, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
-        case EPI_BIAS_RESID: store_tile_out<EPI_BIAS_RESID, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
-        case EPI_MUL_GELU_GRAD: store_tile_out<EPI_MUL_GELU_GRAD, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
-        case EPI_MUL_RELU_MASK: store_tile_out<EPI_MUL_RELU_MASK, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
-        case EPI_BIAS_ROWADD: store_tile_out<EPI_BIAS_ROWADD, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
-        case EPI_ACCUM: store_tile_out<EPI_ACCUM, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
-        default: store_tile_out<EPI_NONE, 2, 2>(p, p.C, acc, mbase, nbase, half); break;
+        case EPI_BIAS: store_tile_out<EPI_BIAS, 2, 2>(p, Cb, acc, mbase, nbase, half); break;
+        case EPI_BIAS_RELU: store_tile_out<EPI_BIAS_RELU, 2, 2>(p, Cb, acc, mbase, nbase, half); break;
+        case EPI_BIAS_GELU: store_tile_out<EPI_BIAS_GELU, 2, 2>(p, Cb, acc, mbase, nbase, half); break;
+        case EPI_BIAS_RESID: store_tile_out<EPI_BIAS_RESID, 2, 2>(p, Cb, acc, mbase, nbase, half); break;
+        case EPI_MUL_GELU_GRAD: store_tile_out<EPI_MUL_GELU_GRAD, 2, 2>(p, Cb, acc, mbase, nbase, half); break;
+        case EPI_MUL_RELU_MASK: store_tile_out<EPI_MUL_RELU_MASK, 2, 2>(p, Cb, acc, mbase, nbase, half); break;
+        case EPI_BIAS_ROWADD: store_tile_out<EPI_BIAS_ROWADD, 2, 2>(p, Cb, acc, mbase, nbase, half); break;
+        case EPI_ACCUM: store_tile_out<EPI_ACCUM, 2, 2>(p, Cb, acc, mbase, nbase, half); break;
+        default: store_tile_out<EPI_NONE, 2, 2>(p, Cb, acc, mbase, nbase, half); break;
     }
     }
 #ifdef D2S_STAMPS
@@ -344,11 +373,11 @@ int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace,
     const bool af32 = p.vecA && a_inkernel_env != 0;
     if (split == 3) {
         if (!af32) hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)((ea + 255) / 256)), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
-        if (b_cols) hipLaunchKernelGGL(split_cols_kernel<3>, dim3((p.N + 31) / 32, Kp / 32), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp);
+        if (b_cols) hipLaunchKernelGGL(split_cols_kernel<3>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
         else hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)((eb + 255) / 256)), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
     } else {
         if (!af32) hipLaunchKernelGGL(split_rows_kernel<1>, dim3((unsigned)((ea + 255) / 256)), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
-        if (b_cols) hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.N + 31) / 32, Kp / 32), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp);
+        if (b_cols) hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
         else hipLaunchKernelGGL(split_rows_kernel<1>, dim3((unsigned)((eb + 255) / 256)), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
     }
     const int tiles = ((p.M + SBM - 1) / SBM) * ((p.N + SBN - 1) / SBN);
@@ -357,6 +386,8 @@ int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace,
     if (lds < 4 * epi_stage_floats(2) * sizeof(float)) lds = 4 * epi_stage_floats(2) * sizeof(float);
     GemmArgs pv = p;
     pv.vec_epilogue = epilogue_vec_ok(p) ? 1 : 0;
+    pv.k_per_slice = Kp;      // one K slice over the padded reduction length
+    pv.slab_stride = 0;
     PieceArgs q{Ap, Bp, Kp};
 #define D2S_LAUNCH_PIECES(S, K_, F) hipLaunchKernelGGL((gemm_pieces_nt_kernel<S, K_, F>), dim3(tiles), block, lds, stream, pv, q)
     if (af32) {
@@ -371,6 +402,30 @@ int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace,
         else D2S_LAUNCH_PIECES(1, 16, false);
     }
 #undef D2S_LAUNCH_PIECES
+    return d2s_check_launch();
+}
+
+// wgrad on the bf16 matrix cores (mode 2): C slabs[z][M][N] = A^T B over K slice z, with A given as [K][M] and B as [K][N] (both
+// token-major).  Both operands go through the transposing split pass, so the matrix kernel sees K-contiguous pieces as usual.
+// The caller (gemm_f32.hip) combines the slabs in slab order.  Workspace: pieces only (the slabs are the caller's).
+size_t split_tn_pieces_bytes(int split, int M, int N, int K) { return split_workspace_bytes(split, M, N, K); }
+
+int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_ws, hipStream_t stream) {
+    const int Kp = ((p.K + 31) / 32) * 32;
+    if (split != 1) return D2S_ERR_ARG;
+    if ((long)p.M * Kp * 2 >= (1L << 32) || (long)p.N * Kp * 2 >= (1L << 32)) return D2S_ERR_ARG;
+    __bf16* Ap = static_cast<__bf16*>(pieces_ws);
+    __bf16* Bp = reinterpret_cast<__bf16*>(static_cast<unsigned char*>(pieces_ws) + align256((size_t)split * p.M * Kp * sizeof(__bf16)));
+    dim3 block(256);
+    hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.M + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
+    hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
+    const int tiles = ((p.M + SBM - 1) / SBM) * ((p.N + SBN - 1) / SBN);
+    size_t lds = (size_t)split * (SBM + SBN) * (32 + 8) * sizeof(__bf16);
+    if (lds < 4 * epi_stage_floats(2) * sizeof(float)) lds = 4 * epi_stage_floats(2) * sizeof(float);
+    GemmArgs pv = p;                      // p.C / p.ldc / p.slab_stride / p.k_per_slice / p.epi were set by the caller
+    pv.vec_epilogue = (epilogue_vec_ok(p) && (p.slab_stride % 4 == 0)) ? 1 : 0;
+    PieceArgs q{Ap, Bp, Kp};
+    hipLaunchKernelGGL((gemm_pieces_nt_kernel<1, 32, false>), dim3(tiles, 1, slices), block, lds, stream, pv, q);
     return d2s_check_launch();
 }
 

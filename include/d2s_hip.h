@@ -38,7 +38,8 @@ typedef struct ihipStream_t* d2s_stream_t; /* == hipStream_t */
  * epilogue: 0 none, 1 +bias[n], 2 relu(+bias), 3 gelu(+bias) with pre-activation copy to aux_out, 4 +bias+aux[m][n],
  *           5 *gelu'(aux[m][n]), 6 *(aux[m][n] > 0), 7 +bias+aux[m % aux_rows][n] (pos_embed add), 8 C += acc.
  * remap_rows_per_img/remap_skip: output row m goes to m + (m / rows_per_img + 1) * skip (leave room for CLS rows). */
-/* GEMM arithmetic mode for the NT / NN layouts (wgrad always uses the exact kernel): 0 = exact fp32 MFMA; 1 = "bf16x3 split":
+/* GEMM arithmetic mode (NT / NN layouts in modes 1 and 2; the weight gradient follows in mode 2 only, its bias gradient stays an
+ * exact fp32 column sum): 0 = exact fp32 MFMA; 1 = "bf16x3 split":
  * each fp32 operand is split into three bf16 pieces in registers and the 6 significant cross products run on the bf16 matrix
  * cores with fp32 accumulation (error ~2^-24 per product, fp32-class; 416 TFLOP/s effective peak); 2 = bf16 operands, fp32
  * accumulation (BASELINE config 5's bf16 regime).  Inputs and outputs stay fp32 in every mode. */

@@ -315,3 +315,28 @@ def test_gemm_split_modes(ops, mode, rtol, atol):
             np.testing.assert_allclose(got.numpy(), (ref32 + r).numpy(), rtol=rtol, atol=atol)
     finally:
         lib.load().d2s_set_gemm_mode(0)
+
+
+@pytest.mark.parametrize("tokens,n_out,n_in", [(197 * 8, 384, 1536), (1000, 96, 192), (130, 10, 24), (4100, 200, 72)])
+def test_linear_wgrad_bf16_mode(ops, tokens, n_out, n_in):
+    """Mode 2 runs the weight gradient on the bf16 matrix cores (transposing split + K-sliced pieces kernel + ordered combine);
+    the bias gradient stays an exact fp32 column sum.  Tolerance: bf16 operand rounding (2^-9 relative per product)."""
+    g = torch.Generator().manual_seed(tokens + n_in)
+    dy = torch.randn(tokens, n_out, generator=g)
+    x = torch.randn(tokens, n_in, generator=g)
+    ref_w = dy.double().t() @ x.double()
+    ref_b = dy.double().sum(0)
+    ops.set_gemm_mode(ops.GEMM_BF16)
+    try:
+        dW = torch.empty(n_out, n_in, device=_dev())
+        db = torch.empty(n_out, device=_dev())
+        ops.linear_wgrad(dy.to(_dev()), x.to(_dev()), dW, db=db)
+        scale = math.sqrt(tokens)          # rms magnitude of an entry of dy^T x
+        assert (dW.cpu().double() - ref_w).abs().max() <= 0.02 * scale
+        assert (dW.cpu().double() - ref_w).pow(2).mean().sqrt() <= 0.004 * scale
+        assert (db.cpu().double() - ref_b).abs().max() <= 2e-6 * scale * 10
+        ops.linear_wgrad(dy.to(_dev()), x.to(_dev()), dW, db=db, accumulate=True)
+        assert (dW.cpu().double() - 2 * ref_w).abs().max() <= 0.04 * scale
+        assert (db.cpu().double() - 2 * ref_b).abs().max() <= 4e-6 * scale * 10
+    finally:
+        ops.set_gemm_mode(ops.GEMM_EXACT)
