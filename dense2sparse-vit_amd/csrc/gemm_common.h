@@ -29,7 +29,7 @@ struct GemmArgs {
     int vecA, vecB;    // 16-byte vector loads allowed for A / B
     // output row remap (patch embed writes token t of image b to row b*(T+1)+1+t): out_row = m + m / rows_per_img * skip + skip0
     int remap_rows_per_img; int remap_skip;
-    int stagger;       // de-synchronise the first residency round (speed only)
+    int stagger;       // unused (a first-round stagger of co-resident workgroups was measured slower)
     int vec_epilogue;  // 16-byte LDS-staged epilogue allowed (see epilogue_vec_ok)
     float* colsum;     // TN only: column sums of the A operand (bias gradient), one slab of M floats per K slice; may be null
     int colsum_accumulate;

@@ -23,6 +23,18 @@ using namespace d2s_gemm;
 
 constexpr int BK = 16;
 
+#ifdef D2S_STAMPS   // diagnostic build only: per-workgroup {entry, loop begin, loop end, exit} in 100 MHz ticks, loop cycles, hardware id
+__device__ unsigned long long g_stamps_f32[8 * 65536];
+#define FSTAMP(i) if (threadIdx.x == 0 && blockIdx.x < 65536 && blockIdx.z == 0) g_stamps_f32[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime()
+#define FSTAMPC(i) if (threadIdx.x == 0 && blockIdx.x < 65536 && blockIdx.z == 0) g_stamps_f32[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime()
+#define FSTAMPID(i) if (threadIdx.x == 0 && blockIdx.x < 65536 && blockIdx.z == 0) g_stamps_f32[8 * blockIdx.x + (i)] = \
+    ((unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4)) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32)
+#else
+#define FSTAMP(i)
+#define FSTAMPC(i)
+#define FSTAMPID(i)
+#endif
+
 template <int LAY, int BR>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, int row0, int k0, int rows, int kend,
                                           int vec, int tid, f32x4 (&r)[BR / 64]) {
@@ -110,6 +122,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 1) void gemm_f3
     float* Bs = smem + 2 * BK * BM;   // [2][BK][BN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    FSTAMP(0); FSTAMPID(6);
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware tile order: consecutive workgroups (same XCD every 8) walk along N for one M panel so that the
@@ -127,22 +140,6 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 1) void gemm_f3
     const int kbeg = blockIdx.z * p.k_per_slice;
     const int kend = min(p.K, kbeg + p.k_per_slice);
     const int nk = (kend - kbeg + BK - 1) / BK;
-
-    // De-synchronise the first residency round.  All workgroups of a launch do identical work, so the RES workgroups that
-    // share a CU start together, share its matrix pipes evenly and would reach their prologue / epilogue (which cannot
-    // overlap their own MFMAs) at the same moment, every round.  Workgroup b and b + 256 tend to share a CU, so slot
-    // j = (b / 256) % RES is delayed once by j x (the MFMA time of one tile running alone); after that the slots stay out
-    // of phase and one workgroup's gaps hide under the others' matrix work.  Only timing depends on it.
-    if (p.stagger) {
-        constexpr int RES = (BM == 128 && BN == 128) ? 3 : (BM == 64 && BN == 64) ? 8 : 5;
-        const int lin = blockIdx.z * gridDim.x + blockIdx.x;
-        if (lin < 256 * RES) {
-            const int j = (lin >> 8) % RES;
-            const long wait_cycles = (long)j * nk * (BK / 2) * MT * NT * 64;
-            const long t0 = (long)__builtin_amdgcn_s_memtime();
-            while ((long)__builtin_amdgcn_s_memtime() - t0 < wait_cycles) __builtin_amdgcn_s_sleep(32);
-        }
-    }
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -187,6 +184,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 1) void gemm_f3
     }
     __syncthreads();
 
+    FSTAMP(1); FSTAMPC(4);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if constexpr (FAST) {   // branch-free prefetch (the last trip re-reads the last slab and discards it)
@@ -268,12 +266,17 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 1) void gemm_f3
         __syncthreads();
     }
 
+    FSTAMP(2); FSTAMPC(5);
     // ---- epilogue: the (wave-uniform) epilogue kind is resolved ONCE, each kind has its own straight-line store loop ----
     float* Cb = p.C + (long)blockIdx.z * p.slab_stride;
     const int epi = (gridDim.z > 1) ? (int)EPI_NONE : p.epi;
     static_assert(4 * epi_stage_floats(NT) <= 2 * BK * (BM + BN), "epilogue staging must fit the operand buffers");
     if (p.vec_epilogue) {   // operand LDS is free after the loop's final barrier
         store_tile_dispatch_lds<MT, NT>(epi, p, Cb, acc, row0 + wm * WM, col0 + wn * WN, lane, smem + wave * epi_stage_floats(NT));
+#ifdef D2S_STAMPS
+        __builtin_amdgcn_s_waitcnt(0);
+        FSTAMP(3);
+#endif
         return;
     }
     const int mbase = row0 + wm * WM, nbase = col0 + wn * WN + l31;
@@ -412,6 +415,12 @@ static int splitk_slices(int tiles, int K) {
     return slices;
 }
 
+#ifdef D2S_STAMPS
+extern "C" int d2s_debug_read_stamps_f32(unsigned long long* host_out, int n_wg) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps_f32), (size_t)n_wg * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" {
 
 // Workspace needed by d2s_gemm_f32 for a given problem (only the TN / wgrad layout splits K).
@@ -449,8 +458,7 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
     p.remap_rows_per_img = remap_rows_per_img; p.remap_skip = remap_skip;
     p.colsum = nullptr; p.colsum_accumulate = accumulate;
     {
-        static const int stagger_env = [] { const char* e = getenv("D2S_GEMM_STAGGER"); return e ? atoi(e) : 0; }();   // experiment knob; measured: no gain
-        p.stagger = stagger_env;
+        p.stagger = 0;
         p.vec_epilogue = 0;
     }
     const int alay = layout == 2 ? 1 : 0, blay = layout == 0 ? 0 : 1;
