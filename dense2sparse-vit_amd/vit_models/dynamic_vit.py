@@ -364,29 +364,32 @@ class VisionTransformerTeacher(_ViTBase):
 
 
 def resize_pos_embed(posemb, posemb_new):
-    """:1178-1195 - bilinear resize of the grid part of a position embedding (checkpoint ingestion, host side)."""
-    ntok_new = posemb_new.shape[1] - 1
-    posemb_tok, posemb_grid = posemb[:, :1], posemb[0, 1:]
-    gs_old, gs_new = int(math.sqrt(len(posemb_grid))), int(math.sqrt(ntok_new))
-    posemb_grid = posemb_grid.reshape(1, gs_old, gs_old, -1).permute(0, 3, 1, 2)
-    posemb_grid = F.interpolate(posemb_grid, size=(gs_new, gs_new), mode='bilinear')
-    posemb_grid = posemb_grid.permute(0, 2, 3, 1).reshape(1, gs_new * gs_new, -1)
-    return torch.cat([posemb_tok, posemb_grid], dim=1)
+    """Position-embedding table of a checkpoint trained at another resolution -> this model's grid (reference :1178-1195): the CLS
+    row is kept, the square patch grid is resampled bilinearly (align_corners=False).  Host side, runs once at load time."""
+    cls_row, grid = posemb[:, :1], posemb[0, 1:]
+    side_old = int(math.sqrt(grid.shape[0]))
+    side_new = int(math.sqrt(posemb_new.shape[1] - 1))
+    dim = grid.shape[-1]
+    grid = grid.t().reshape(1, dim, side_old, side_old)                               # [1, D, h, w]
+    grid = F.interpolate(grid, size=(side_new, side_new), mode='bilinear')
+    grid = grid.reshape(dim, side_new * side_new).t().unsqueeze(0)                    # [1, h'w', D]
+    return torch.cat([cls_row, grid], dim=1)
 
 
 def checkpoint_filter_fn(state_dict, model):
-    """:1198-1213."""
-    out = {}
-    if 'model' in state_dict:
-        state_dict = state_dict['model']
-    for k, v in state_dict.items():
-        if 'patch_embed.proj.weight' in k and len(v.shape) < 4:
-            O, I, H, W = model.patch_embed.proj.weight.shape
-            v = v.reshape(O, -1, H, W)
-        elif k == 'pos_embed' and v.shape != model.pos_embed.shape:
-            v = resize_pos_embed(v, model.pos_embed)
-        out[k] = v
-    return out
+    """Make a DeiT-style checkpoint loadable (reference :1198-1213): unwrap {'model': ...}, give a patch-projection weight stored as a
+    matrix its conv shape, and resample a position table of a different resolution."""
+    source = state_dict.get('model', state_dict)
+    conv_shape = model.patch_embed.proj.weight.shape
+
+    def adapt(key, value):
+        if 'patch_embed.proj.weight' in key and value.dim() < 4:
+            return value.reshape(conv_shape[0], -1, conv_shape[2], conv_shape[3])
+        if key == 'pos_embed' and value.shape != model.pos_embed.shape:
+            return resize_pos_embed(value, model.pos_embed)
+        return value
+
+    return {key: adapt(key, value) for key, value in source.items()}
 
 
 def _load_local(model, checkpoint_path, strict):

@@ -123,3 +123,33 @@ def test_cli_rejects_flags_outside_the_path():
     a = utils.parse_args([])
     mask_predictor.check_supported(a)
     assert a.mixup == 0.0 and a.cutmix == 0.0
+
+
+def test_checkpoint_ingestion_matches_reference_fixture():
+    """checkpoint_filter_fn + resize_pos_embed against the reference's own output on a synthetic DeiT-style checkpoint
+    (tests/golden/checkpoint.npz, tools/gen_golden.py::gen_checkpoint_ingestion): {'model': ...} unwrapping, matrix -> conv patch
+    projection, 4x4 -> 6x6 position grid."""
+    import types
+    import vit_models
+    z = np.load(os.path.join(REPO, "tests", "golden", "checkpoint.npz"))
+    sd_in = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in.")}
+    want = {k[4:]: z[k] for k in z.files if k.startswith("out.")}
+    D, P = 16, 4
+    model = types.SimpleNamespace(patch_embed=types.SimpleNamespace(proj=types.SimpleNamespace(weight=torch.zeros(D, 3, P, P))),
+                                  pos_embed=torch.zeros(1, 37, D))
+    got = vit_models.checkpoint_filter_fn({"model": sd_in}, model)
+    assert set(got) == set(want)
+    for k in want:
+        assert tuple(got[k].shape) == want[k].shape, k
+        np.testing.assert_allclose(got[k].numpy(), want[k], rtol=1e-6, atol=1e-7, err_msg=k)
+    # and through the factory: a local file, loaded with weights_only=True
+    import tempfile
+    m = vit_models.dynamic_vit_tiny_patch16_224_teacher()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["pos_embed"] = torch.randn(1, 1 + 7 * 7, 192)           # a 112 x 112 checkpoint
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "ckpt.pth")
+        torch.save({"model": sd}, path)
+        m2 = vit_models.dynamic_vit_tiny_patch16_224_teacher(checkpoint_path=path)
+    assert m2.pos_embed.shape == (1, 197, 192)
+    np.testing.assert_allclose(m2.pos_embed[:, :1].detach().numpy(), sd["pos_embed"][:, :1].numpy())

@@ -324,6 +324,20 @@ def gen_t2t():
     print(f"[golden] t2t: {len(out)} arrays")
 
 
+def gen_checkpoint_ingestion(dv):
+    """checkpoint_filter_fn / resize_pos_embed of the reference (dynamic_vit.py:1178-1213) on a synthetic DeiT-style checkpoint: a
+    {'model': ...} wrapper, a patch projection stored as a matrix, and a 4x4-grid position table loaded into a 6x6-grid model."""
+    normal = lambda name, shape, std: synth.normal(name, shape, std=std, seed=11)
+    D, P = 16, 4
+    model = types.SimpleNamespace(patch_embed=types.SimpleNamespace(proj=types.SimpleNamespace(weight=torch.zeros(D, 3, P, P))),
+                                  pos_embed=torch.zeros(1, 1 + 36, D))
+    sd = {"pos_embed": _t(normal("ckpt.pos", (1, 1 + 16, D), 0.5)), "patch_embed.proj.weight": _t(normal("ckpt.proj", (D, 3 * P * P), 0.1)),
+          "head.bias": _t(normal("ckpt.hb", (10,), 0.1))}
+    out = dv.checkpoint_filter_fn({"model": dict(sd)}, model)
+    np.savez_compressed(os.path.join(OUT, "checkpoint.npz"), **{"in." + k: _np(v) for k, v in sd.items()}, **{"out." + k: _np(v) for k, v in out.items()})
+    print("checkpoint.npz", {k: tuple(v.shape) for k, v in out.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -333,6 +347,7 @@ def main():
     gen_perturbed_topk(ptk)
     gen_micro_intermediates(dv)
     gen_t2t()
+    gen_checkpoint_ingestion(dv)
     for name in cases.MODEL_CASES:
         gen_model_case(dv, losses, name)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
