@@ -239,6 +239,45 @@ def test_full_size_properties_deit_small_batch128():
     assert torch.isfinite(logits).all()
 
 
+def test_full_size_train_step_deterministic_and_batch_independent():
+    """The headline workload at full size (DeiT-S 224, keep 0.5 @ block 3, batch 128), properties that hold at any size:
+    (1) determinism - the same step from the same state gives bit-identical losses and gradients (ordered split-K combine, no
+    atomics anywhere on the path); (2) batch independence - images are independent end to end (the property data parallelism
+    rests on): the first 64 images give the same logits, kept ids and CLS-attention rows whether they run alone or inside the
+    batch of 128; (3) every teacher CLS-attention row is a probability distribution."""
+    import vit_models
+    from d2s import synth
+    from d2s.engine import TrainStep
+    dev = torch.device("cuda:0")
+    B = 128
+    torch.manual_seed(0)
+    student = vit_models.dynamic_vit_small_patch16_224_student([3], [0.5], topk_selection=True, predictor_loss_type="kl_div").to(dev)
+    teacher = vit_models.dynamic_vit_small_patch16_224_teacher().to(dev)
+    args = types.SimpleNamespace(keep_ratios=[0.5], mask_loss_type="kl_div", mixup=0.0, patch_score_threshold=None, step=0)
+    ts = TrainStep(student, teacher, args, warmup_steps=0)
+    x = _t(synth.images(B, 3, 224, seed=1)).to(dev)
+    y = _t(synth.labels(B, 1000, seed=1)).to(dev)
+    student.train()
+    runs = []
+    for _ in range(2):
+        loss, info = ts.forward_losses(x, y)
+        ts.opt.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.detach().clone(), info["kept"][0].clone(), info["logits_s"].detach().clone(), ts.arena.grads.clone(),
+                     info["cls_attn"].clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    assert torch.equal(runs[0][3], runs[1][3]), "gradients differ between two identical steps"
+    assert torch.isfinite(runs[0][3]).all() and float(runs[0][3].abs().max()) > 0
+    cls_attn = runs[0][4]                                                     # [B, 12, H, 197]
+    np.testing.assert_allclose(cls_attn.sum(dim=-1).cpu().numpy(), np.ones(cls_attn.shape[:-1], np.float32), rtol=2e-5)
+    with torch.no_grad():
+        _, half = ts.forward_losses(x[:64].contiguous(), y[:64].contiguous())
+    np.testing.assert_array_equal(half["kept"][0].cpu().numpy(), runs[0][1][:64].cpu().numpy())
+    np.testing.assert_allclose(half["logits_s"].cpu().numpy(), runs[0][2][:64].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(half["cls_attn"].cpu().numpy(), cls_attn[:64].cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
 @pytest.mark.parametrize("name", ["micro2", "small_k50"])
 def test_split_gemm_mode_keeps_fp32_parity(name):
     """GEMM mode 1 (bf16x3 split on the bf16 matrix cores): same assertions as the exact mode - kept ids bit-exact against the
