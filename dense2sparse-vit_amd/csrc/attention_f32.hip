@@ -65,12 +65,20 @@ __device__ __forceinline__ void mma_lds_reg(const float* __restrict__ S, int l31
     }
 }
 // out[dt] += X^T-style product: A operand = accumulator-layout registers p[r], B operand = LDS tile row mfma32_row(r,half)
-__device__ __forceinline__ void mma_reg_lds(const f32x16& p, const float* __restrict__ S, int l31, int half, f32x16 (&o)[2]) {
+// `groups` (wave-uniform, 1..4): only tile rows < 8 * groups carry non-zero p (the last, partial tile of a sequence): registers
+// 4g..4g+3 cover rows [8g, 8g + 8), so whole groups of MFMAs whose A operand is exactly zero are skipped (bit-identical result).
+__device__ __forceinline__ void mma_reg_lds(const f32x16& p, const float* __restrict__ S, int l31, int half, f32x16 (&o)[2],
+                                            int groups = 4) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float* row = &S[mfma32_row(r, half) * PITCH];
-        o[0] = mfma32(p[r], row[l31], o[0]);
-        o[1] = mfma32(p[r], row[32 + l31], o[1]);
+    for (int g = 0; g < 4; ++g) {
+        if (g < groups) {
+#pragma unroll
+            for (int r = 4 * g; r < 4 * g + 4; ++r) {
+                const float* row = &S[mfma32_row(r, half) * PITCH];
+                o[0] = mfma32(p[r], row[l31], o[0]);
+                o[1] = mfma32(p[r], row[32 + l31], o[1]);
+            }
+        }
     }
 }
 
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const float* __restric
             o[0][r] *= a;
             o[1][r] *= a;
         }
-        mma_reg_lds(s, Vs, l31, half, o);
+        mma_reg_lds(s, Vs, l31, half, o, min(4, (n - kv0 + 7) >> 3));
     }
     if (!active) return;
     const float inv_l = 1.0f / l_run;
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const float* __rest
             const float p = (kv0 + mfma32_row(r, half) < n) ? __expf(s[r] - lse_i) : 0.f;
             s[r] = p * (dp[r] - dl_i);          // dS^T
         }
-        mma_reg_lds(s, Ks, l31, half, dq);      // dQ[query][d] += sum_key dS^T[key][query] K[key][d]
+        mma_reg_lds(s, Ks, l31, half, dq, min(4, (n - kv0 + 7) >> 3));      // dQ[query][d] += sum_key dS^T[key][query] K[key][d]
     }
     if (!active) return;
     float* dqb = dqkv + (long)b * n * ld + h * DH;
@@ -322,8 +330,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
             s[r] = p;
             dp[r] = p * (dp[r] - dl_s[qi]);
         }
-        mma_reg_lds(s, Ds, l31, half, dv);     // dV[key][d] += sum_query P[query][key] dO[query][d]
-        mma_reg_lds(dp, Qs, l31, half, dk);    // dK[key][d] += sum_query dS[query][key] Q[query][d]
+        const int qgroups = min(4, (n - t * 32 + 7) >> 3);          // query rows of this tile that exist
+        mma_reg_lds(s, Ds, l31, half, dv, qgroups);     // dV[key][d] += sum_query P[query][key] dO[query][d]
+        mma_reg_lds(dp, Qs, l31, half, dk, qgroups);    // dK[key][d] += sum_query dS[query][key] Q[query][d]
     }
     if (!active) return;
     float* dkb = dqkv + (long)b * n * ld + (long)H * DH + h * DH;
