@@ -260,6 +260,9 @@ class TrainStep:
         if self.reducer is not None:
             student.grad_ready_hook = lambda i: self.reducer.ready_from(self.block_offset[i])
         self.frozen = frozenset(n for n, p in student.named_parameters() if not p.requires_grad)
+        import os
+        two = os.environ.get("D2S_TEACHER_STREAM", "0") == "1" and self.arena.params.is_cuda
+        self._teacher_stream = torch.cuda.Stream() if two else None
         self.set_epoch(0)
 
     def set_epoch(self, epoch):
@@ -268,9 +271,20 @@ class TrainStep:
         return adjust_learning_rate(self.opt, self.student, epoch, self.epochs, self.lr, self.min_lr, self.warmup_steps, self.frozen)
 
     def forward_losses(self, images, labels):
-        with torch.no_grad():
-            logits_t, token_t, cls_attn = self.teacher(images)
-        logits_s, token_s, pred_logits, kept = self.student(images)
+        if self._teacher_stream is not None and ops.get_gemm_mode() == ops.GEMM_EXACT:
+            # The frozen teacher's forward and the student's forward are independent until the losses: the teacher runs on a second
+            # HIP stream so that its kernels fill the CUs the student's kernels leave idle in their ramp-up / last residency round
+            # (and vice versa).  Exact mode only: there no forward kernel uses the shared scratch buffer.
+            side, main = self._teacher_stream, torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad():
+                logits_t, token_t, cls_attn = self.teacher(images)
+            logits_s, token_s, pred_logits, kept = self.student(images)
+            main.wait_stream(side)
+        else:
+            with torch.no_grad():
+                logits_t, token_t, cls_attn = self.teacher(images)
+            logits_s, token_s, pred_logits, kept = self.student(images)
         mask_loss = self.mask_loss_fn(pred_logits, cls_attn, kept, self.metrics)
         backbone_loss = self.backbone_loss_fn(logits_s, token_s, logits_t, token_t, kept, labels, self.metrics)
         loss = mask_loss if self.epoch < self.warmup_steps else backbone_loss + mask_loss     # train.py:50-53

@@ -340,7 +340,7 @@ GEMM_EXACT, GEMM_SPLIT, GEMM_BF16 = 0, 1, 2
 
 def set_gemm_mode(mode):
     """0 exact fp32 MFMA (default, bit-for-bit an fp32 fma chain); 1 bf16x3 split on the bf16 matrix cores (fp32-class accuracy);
-    2 bf16 operands with fp32 accumulation.  Affects forward / dgrad GEMMs; wgrad always uses the exact kernel."""
+    2 bf16 operands with fp32 accumulation (forward, dgrad and - in this mode only - wgrad GEMMs)."""
     lib.load().d2s_set_gemm_mode(int(mode))
 
 
