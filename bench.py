@@ -100,6 +100,25 @@ class KernelTimer:
             timer.records.setdefault(("gather_pack", ""), []).append((s, e, B * (2.0 * (k + 1) * D * 4 + 8.0 * k)))
             return out
 
+        def timed(fn, key, work_of):
+            def wrapper(*a, **kw):
+                if not timer.enabled:
+                    return fn(*a, **kw)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = fn(*a, **kw)
+                e.record()
+                timer.records.setdefault(key, []).append((s, e, work_of(*a, **kw)))
+                return out
+            return wrapper
+
+        # HBM-bound kernels: algorithmic bytes = what the kernel must read + write once
+        ops.layernorm_bwd = timed(ops.layernorm_bwd, ("layernorm_bwd", ""),
+                                  lambda x, rowmap, dy, w, mean, rstd, dx, add_src, dw, db, rows, D, *a, **kw:
+                                  rows * D * 4.0 * (3 + (1 if add_src is not None else 0)))
+        ops.layernorm_fwd = timed(ops.layernorm_fwd, ("layernorm_fwd", ""), lambda x, rowmap, w, b, rows, D, eps: rows * D * 8.0)
+        ops.adamw_step = timed(ops.adamw_step, ("adamw", ""), lambda params, *a, **kw: params.numel() * 28.0)
+
         orig_wgrad = ops.linear_wgrad
 
         def linear_wgrad(dy, x, dW, *a, **kw):
@@ -387,6 +406,13 @@ def main():
                               "bytes_per_launch": ga["work"] / ga["launches"], "avg_launch_us": round(1000.0 * ga["ms"] / ga["launches"], 2),
                               "traffic": pmc_traffic("gather_pack_kernel"), "at_batch_2048": gather_large(device),
                               "back_to_back_hbm_cold": gather_back_to_back(device, args.batch, k=int(196 * args.keep)) if args.config == "headline" else None}
+        for key, kern in ((("layernorm_bwd", ""), "ln_bwd_kernel (+ fold)"), (("layernorm_fwd", ""), "ln_fwd_kernel"), (("adamw", ""), "adamw_kernel")):
+            rec = summ.get(key)
+            if rec:
+                gbs = rec["work"] / (rec["ms"] * 1e-3) / 1e9
+                line[key[0]] = {"bound": "hbm", "kernel": kern, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": round(gbs / PEAK_HBM_GBS, 4), "launches_per_step": rec["launches"] / args.steps,
+                                "ms_per_step": round(rec["ms"] / args.steps, 3)}
         line["hbm_copy_GBps_measured"] = hbm_copy_gbs(device)
         if distributed:
             c = ts.reducer.comm_summary(args.steps)
