@@ -316,6 +316,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *cp = accumulate ? (*cp + s) : s;
 }
 
+// Split-K combine for the forward / dgrad layouts: sums the slabs in slab order and applies the epilogue the single-pass kernel
+// would have applied in its store (bias, ReLU / GELU (+ pre-activation copy), residual, activation-gradient masks, positional row add
+// with the CLS row remap, accumulate).  `p` carries the REAL output (C, ldc) and epilogue operands.
+__global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(GemmArgs p, const float* __restrict__ ws, int slabs, long slab_stride) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)p.M * p.N) return;
+    const int m = (int)(idx / p.N), n = (int)(idx % p.N);
+    float v = 0.f;
+    for (int z = 0; z < slabs; ++z) v += ws[(long)z * slab_stride + idx];
+    const int e = p.epi;
+    const bool has_bias = e == EPI_BIAS || e == EPI_BIAS_RELU || e == EPI_BIAS_GELU || e == EPI_BIAS_RESID || e == EPI_BIAS_ROWADD;
+    if (has_bias && p.bias) v += p.bias[n];
+    long orow = m;
+    if (e == EPI_BIAS_ROWADD && p.remap_rows_per_img > 0) orow = (long)m + (long)(m / p.remap_rows_per_img) * p.remap_skip + p.remap_skip;
+    float* cp = p.C + orow * p.ldc + n;
+    if (e == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+    if (e == EPI_BIAS_GELU) {
+        if (p.aux_out) p.aux_out[(long)m * p.ldc + n] = v;
+        v = gelu_erf(v);
+    }
+    if (e == EPI_BIAS_RESID) v += p.aux[(long)m * p.ldaux + n];
+    if (e == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(p.aux[(long)m * p.ldaux + n]);
+    if (e == EPI_MUL_RELU_MASK) v = p.aux[(long)m * p.ldaux + n] > 0.f ? v : 0.f;
+    if (e == EPI_BIAS_ROWADD) v += p.aux[(long)(m % p.aux_rows) * p.ldaux + n];
+    if (e == EPI_ACCUM) v += *cp;
+    *cp = v;
+}
+
 // Column sums (bias gradients): out[n] (+)= sum_m X[m][n].  Stage 1: each block owns 64 columns and a row slice.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long ldx, int M, int N,
                                                              int rows_per_slice, float* __restrict__ part) {
@@ -353,8 +381,11 @@ inline Tile pick_tile(int M, int N) {
     float best_cost = 1e30f;
     for (const Tile& t : cand) {
         const long nwg = (long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
-        const long rounds = (nwg + 255) / 256;
-        const float cost = (float)rounds * t.bm * t.bn * t.penalty;
+        const long per_cu = (nwg + 255) / 256;                      // workgroups the busiest CU gets
+        // one workgroup puts one wave on each SIMD; a single wave cannot keep the matrix pipe busy (dependent MFMAs on its few
+        // accumulators, exposed LDS / barrier latency), two nearly can: small grids should prefer more, smaller workgroups
+        const float pipe = per_cu >= 3 ? 1.0f : per_cu == 2 ? 0.85f : 0.6f;
+        const float cost = (float)per_cu * t.bm * t.bn * t.penalty / pipe;
         if (cost < best_cost) { best_cost = cost; best = t; }
     }
     return best;
@@ -406,6 +437,30 @@ static bool bf16_wgrad() {
 extern "C" size_t d2s_colsum_workspace_bytes(int M, int N);
 extern "C" int d2s_colsum_f32(const float* X, long ldx, int M, int N, float* out, int accumulate, void* workspace,
                               size_t workspace_bytes, hipStream_t stream);
+// Forward / dgrad GEMMs whose tile grid leaves most CUs with 0-2 workgroups (small batches, narrow outputs with a long K) also
+// split K: the choice minimises (workgroups on the busiest CU) x (K share per workgroup) / (matrix-pipe use at that residency) plus a
+// per-slice cost for the extra slab traffic.  Large grids get 1 (no split).  Disabled with the two-stream teacher option, whose
+// forward passes must not share the scratch buffer.
+static int nt_slices(int tiles, int K) {
+    static const int enabled = [] {
+        const char* e = getenv("D2S_NT_SPLITK");
+        const char* t = getenv("D2S_TEACHER_STREAM");
+        return (e ? atoi(e) : 1) && !(t && atoi(t) == 1);
+    }();
+    // only grids that leave the busiest CU with at most 2 workgroups: with more, dispatch evens the load out by itself and the split
+    // only adds slab traffic (measured at B=128: -4...-19 % on the shapes an unrestricted model chose to split)
+    if (!enabled || K < 512 || tiles > 512) return 1;
+    int best = 1;
+    float best_cost = 1e30f;
+    const int smax = K / 256 < 8 ? K / 256 : 8;
+    for (int sl = 1; sl <= smax; ++sl) {
+        const long per_cu = ((long)tiles * sl + 255) / 256;
+        const float pipe = per_cu >= 3 ? 1.0f : per_cu == 2 ? 0.85f : 0.6f;
+        const float cost = (float)per_cu / ((float)sl * pipe) + 0.04f * (sl - 1);
+        if (cost < best_cost - 1e-6f) { best_cost = cost; best = sl; }
+    }
+    return best;
+}
 static int splitk_slices(int tiles, int K) {
     const int target = splitk_target();
     int slices = target >= 100000 ? (target - 100000 + tiles - 1) / tiles : target / tiles;   // >= 100000: round up, else round down
@@ -432,7 +487,11 @@ int d2s_get_gemm_mode(void) { return g_gemm_mode; }
 
 size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K) {
     if (layout != 2 && g_gemm_mode != 0) return split_workspace_bytes(g_gemm_mode == 1 ? 3 : 1, M, N, K);   // bf16 piece matrices
-    if (layout != 2) return 0;
+    if (layout != 2) {
+        const Tile t = pick_tile(M, N);
+        const int sl = nt_slices(((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn), K);
+        return sl > 1 ? (size_t)sl * M * N * sizeof(float) : 0;
+    }
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     const int slices = splitk_slices(tiles, K);
     size_t bytes = slices <= 1 ? 0 : ((size_t)slices * M * N + (size_t)slices * M) * sizeof(float);   // C slabs + fused bias-gradient slabs
@@ -503,17 +562,23 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
     }
     Tile tile = layout == 2 ? Tile{128, 128, 1.f} : pick_tile(M, N);
     const int tiles = ((M + tile.bm - 1) / tile.bm) * ((N + tile.bn - 1) / tile.bn);
-    int slices = 1;
-    if (layout == 2) {
-        slices = splitk_slices(tiles, K);
-    }
+    int slices = layout == 2 ? splitk_slices(tiles, K) : nt_slices(tiles, K);
     int kper = (K + slices - 1) / slices;
     kper = ((kper + BK - 1) / BK) * BK;
     slices = (K + kper - 1) / kper;
     p.k_per_slice = kper;
     p.slab_stride = 0;
     float* realC = C;
-    if (slices > 1) {
+    if (accumulate && layout != 2 && p.epi == EPI_NONE) p.epi = EPI_ACCUM;
+    const GemmArgs real = p;              // output and epilogue operands as the caller gave them (used by the NT / NN slab combine)
+    if (slices > 1 && layout != 2) {
+        const size_t need = (size_t)slices * M * N * sizeof(float);
+        if (!workspace || workspace_bytes < need) return D2S_ERR_WORKSPACE;
+        p.C = static_cast<float*>(workspace);
+        p.ldc = N;
+        p.slab_stride = (long)M * N;
+        p.remap_rows_per_img = 0;
+    } else if (slices > 1) {
         const size_t need = ((size_t)slices * M * N + (size_t)slices * M) * sizeof(float);
         if (!workspace || workspace_bytes < need) return D2S_ERR_WORKSPACE;
         p.C = static_cast<float*>(workspace);
@@ -537,7 +602,11 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
     if (layout == 0) launch_gemm<0, 0>(tile, grid, stream, p, fast);
     else if (layout == 1) launch_gemm<0, 1>(tile, grid, stream, p, fast);
     else launch_gemm<1, 1>(tile, grid, stream, p, fast);
-    if (slices > 1) {
+    if (slices > 1 && layout != 2) {
+        const long total = (long)M * N;
+        hipLaunchKernelGGL(splitk_reduce_epi_kernel, dim3((unsigned)((total + 255) / 256)), block, 0, stream, real,
+                           static_cast<const float*>(workspace), slices, (long)M * N);
+    } else if (slices > 1) {
         const long total = (long)M * N + (colsum_out ? M : 0);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), block, 0, stream,
                            static_cast<const float*>(workspace), realC, ldc, M, N, slices, (long)M * N, accumulate,

@@ -340,3 +340,42 @@ def test_linear_wgrad_bf16_mode(ops, tokens, n_out, n_in):
         assert (db.cpu().double() - 2 * ref_b).abs().max() <= 4e-6 * scale * 10
     finally:
         ops.set_gemm_mode(ops.GEMM_EXACT)
+
+
+@pytest.mark.parametrize("M,N,K", [(600, 384, 1536), (3168, 384, 1536), (257, 96, 2048), (1000, 200, 1024)])
+def test_gemm_small_grid_split_k_epilogues(ops, M, N, K):
+    """Forward / dgrad GEMMs with a small tile grid and a long K split K and apply their epilogue in the ordered slab combine
+    (splitk_reduce_epi_kernel): every epilogue kind must match the single-pass formula."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g) * 0.5
+    w = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    need = ops.lib.query("d2s_gemm_f32_workspace_bytes", 0, M, N, K)
+    assert need > 0, "this shape is expected to take the split-K path"
+    ref = (x.double() @ w.double().t())
+    d = _dev()
+    tol = dict(rtol=2e-4, atol=2e-4)
+    y = ops.linear_fwd(x.to(d), w.to(d), b.to(d)).cpu()
+    np.testing.assert_allclose(y.numpy(), (ref + b.double()).float().numpy(), **tol)
+    y = ops.linear_fwd(x.to(d), w.to(d), b.to(d), epi=ops.EPI_BIAS_RELU).cpu()
+    np.testing.assert_allclose(y.numpy(), torch.relu(ref + b.double()).float().numpy(), **tol)
+    pre = torch.empty(M, N, device=d)
+    y = ops.linear_fwd(x.to(d), w.to(d), b.to(d), epi=ops.EPI_BIAS_GELU, aux_out=pre).cpu()
+    np.testing.assert_allclose(pre.cpu().numpy(), (ref + b.double()).float().numpy(), **tol)
+    np.testing.assert_allclose(y.numpy(), torch.nn.functional.gelu(ref + b.double()).float().numpy(), **tol)
+    y = ops.linear_fwd(x.to(d), w.to(d), b.to(d), epi=ops.EPI_BIAS_RESID, aux=r.to(d)).cpu()
+    np.testing.assert_allclose(y.numpy(), (ref + b.double() + r.double()).float().numpy(), **tol)
+    # dgrad layout with the activation-gradient masks
+    dy = torch.randn(M, N, generator=g) * 0.5
+    w2 = torch.randn(N, K, generator=g) * 0.05          # dx[M,K] = dy[M,N] @ w2[N,K]: reduction length N - use the transposed problem
+    z = torch.randn(M, N, generator=g)
+    dyk = torch.randn(M, K, generator=g) * 0.5
+    wk = torch.randn(K, N, generator=g) * 0.05           # dx[M,N] = dyk[M,K] @ wk[K,N]: reduction length K (long)
+    refd = dyk.double() @ wk.double()
+    got = ops.linear_dgrad(dyk.to(d), wk.to(d), epi=ops.EPI_MUL_RELU_MASK, aux=z.to(d)).cpu()
+    np.testing.assert_allclose(got.numpy(), (refd * (z > 0)).float().numpy(), **tol)
+    zz = z.clone().double().requires_grad_(True)
+    torch.nn.functional.gelu(zz).backward(torch.ones_like(zz))
+    got = ops.linear_dgrad(dyk.to(d), wk.to(d), epi=ops.EPI_MUL_GELU_GRAD, aux=z.to(d)).cpu()
+    np.testing.assert_allclose(got.numpy(), (refd * zz.grad).float().numpy(), **tol)
