@@ -49,7 +49,9 @@ def parse():
                          "B=128; c3 = DeiT-S 3-stage 0.7/0.5/0.3 B=32/GPU; c4 = T2T-ViT-14 keep 0.5 B=64/GPU; c5 = DeiT-B 384^2 keep 0.3 "
                          "bf16 GEMM operands B=64/GPU.  Non-headline presets skip the CPU baseline and set batch / keep / gemm mode.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events (pure step timing)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented pass (no per-kernel figures in the line)")
+    ap.add_argument("--time-kernels-in-region", action="store_true",
+                    help="put the per-kernel HIP events inside the timed region itself (they cost ~5 %% of the step: ~900 event records)")
     a = ap.parse_args()
     a.locs, a.keeps, a.arch, a.img = [3], [a.keep], "deit_small", 224
     if a.config == "c2":
@@ -338,7 +340,11 @@ def main():
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = not args.no_kernel_timing
+    # The timed region runs WITHOUT per-kernel events: ~900 event records per step between the kernels cost about 5 % of the step
+    # (measured: 42.5 vs 40.4 ms), i.e. they would perturb the throughput they sit beside.  The per-kernel figures come from an
+    # identical instrumented pass of the same K steps right after it (same process, same stream, same inputs).
+    in_region = args.time_kernels_in_region and not args.no_kernel_timing
+    timer.enabled = in_region
     if distributed:
         ts.reducer.timing = True
     t0 = time.perf_counter()
@@ -352,6 +358,19 @@ def main():
     timer.enabled = False
     loss = float(info["loss"])
     log(f"timed region done: {args.steps} steps in {elapsed:.3f} s, loss {loss:.5f}")
+    instr_elapsed = elapsed if in_region else None
+    if not args.no_kernel_timing and not in_region:
+        timer.enabled = True
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ts(images, labels)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        instr_elapsed = time.perf_counter() - t1
+        timer.enabled = False
+        log(f"instrumented pass done: {args.steps} steps in {instr_elapsed:.3f} s")
 
     if distributed:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -375,6 +394,11 @@ def main():
                        "global_batch": args.batch * n_gpus, "parallelism": f"dp{n_gpus}", "final_loss": round(loss, 5)},
         }
         summ = timer.summary()
+        if instr_elapsed is not None:
+            line["kernel_timing"] = {"method": "HIP events around every GEMM / gather / scatter / LayerNorm / AdamW launch on the launch stream, "
+                                               + ("inside the timed region" if in_region else
+                                                  "in a second, identical pass of the same K steps after the timed region (the events cost ~5 % of the step)"),
+                                     "instrumented_ms_per_step": round(1000.0 * instr_elapsed / args.steps, 3)}
         gemms = {k: v for k, v in summ.items() if k[0] == "gemm_f32"}
         if gemms:
             tot_ms = sum(v["ms"] for v in gemms.values())
@@ -389,7 +413,7 @@ def main():
                                 "launches_per_step": gemms[dom]["launches"] / args.steps,
                                 "all_gemm_layouts": {k[1]: {"TFLOP/s": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),
                                                             "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in gemms.items()},
-                                "gemm_share_of_step": round(tot_ms / (1000.0 * elapsed), 4),
+                                "gemm_share_of_step": round(tot_ms / (1000.0 * (instr_elapsed or elapsed)), 4),
                                 "gemm_family_TFLOP/s": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2)}
         line["c_abi_calls_per_step"] = round(timer.launch_calls / args.steps, 1)
         sc = summ.get(("scatter_unpack", ""))
@@ -415,7 +439,7 @@ def main():
                                 "ms_per_step": round(rec["ms"] / args.steps, 3)}
         line["hbm_copy_GBps_measured"] = hbm_copy_gbs(device)
         if distributed:
-            c = ts.reducer.comm_summary(args.steps)
+            c = ts.reducer.comm_summary(args.steps * (2 if (instr_elapsed is not None and not in_region) else 1))   # both passes all-reduce
             if c:
                 line["comm"] = c
         if n_gpus == 1 and not args.no_cpu_baseline:
