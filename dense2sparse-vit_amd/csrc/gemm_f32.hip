@@ -439,14 +439,9 @@ extern "C" int d2s_colsum_f32(const float* X, long ldx, int M, int N, float* out
                               size_t workspace_bytes, hipStream_t stream);
 // Forward / dgrad GEMMs whose tile grid leaves most CUs with 0-2 workgroups (small batches, narrow outputs with a long K) also
 // split K: the choice minimises (workgroups on the busiest CU) x (K share per workgroup) / (matrix-pipe use at that residency) plus a
-// per-slice cost for the extra slab traffic.  Large grids get 1 (no split).  Disabled with the two-stream teacher option, whose
-// forward passes must not share the scratch buffer.
+// per-slice cost for the extra slab traffic.  Large grids get 1 (no split).
 static int nt_slices(int tiles, int K) {
-    static const int enabled = [] {
-        const char* e = getenv("D2S_NT_SPLITK");
-        const char* t = getenv("D2S_TEACHER_STREAM");
-        return (e ? atoi(e) : 1) && !(t && atoi(t) == 1);
-    }();
+    static const int enabled = [] { const char* e = getenv("D2S_NT_SPLITK"); return e ? atoi(e) : 1; }();
     // only grids that leave the busiest CU with at most 2 workgroups: with more, dispatch evens the load out by itself and the split
     // only adds slab traffic (measured at B=128: -4...-19 % on the shapes an unrestricted model chose to split)
     if (!enabled || K < 512 || tiles > 512) return 1;

@@ -271,10 +271,10 @@ class TrainStep:
         return adjust_learning_rate(self.opt, self.student, epoch, self.epochs, self.lr, self.min_lr, self.warmup_steps, self.frozen)
 
     def forward_losses(self, images, labels):
-        if self._teacher_stream is not None and ops.get_gemm_mode() == ops.GEMM_EXACT:
+        if self._teacher_stream is not None:
             # The frozen teacher's forward and the student's forward are independent until the losses: the teacher runs on a second
             # HIP stream so that its kernels fill the CUs the student's kernels leave idle in their ramp-up / last residency round
-            # (and vice versa).  Exact mode only: there no forward kernel uses the shared scratch buffer.
+            # (and vice versa).  Scratch buffers are per stream (ops.workspace), so the two forwards never share one.
             side, main = self._teacher_stream, torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side), torch.no_grad():

@@ -14,8 +14,9 @@ _ws = {}
 
 
 def workspace(nbytes, device):
-    """Grow-only scratch buffer per device.  All d2s kernels run on one stream, so reuse is ordered."""
-    key = (device.type, device.index)
+    """Grow-only scratch buffer per (device, stream): kernels of one stream reuse it in order, kernels of different streams (the
+    optional teacher stream, d2s.engine) never share one."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
