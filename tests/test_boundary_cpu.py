@@ -73,7 +73,7 @@ def test_product_never_imports_oracle():
     pkg = os.path.join(REPO, "dense2sparse-vit_amd")
     for root, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith(".py") and f != "smoke.py":      # smoke.py is the driver's checker entry, allowed by contract
+            if f.endswith(".py"):                         # no exception: the smoke checker lives in __graft_entry__.py
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), f"{f} references the oracle"
 
