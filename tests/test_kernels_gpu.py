@@ -379,3 +379,44 @@ def test_gemm_small_grid_split_k_epilogues(ops, M, N, K):
     torch.nn.functional.gelu(zz).backward(torch.ones_like(zz))
     got = ops.linear_dgrad(dyk.to(d), wk.to(d), epi=ops.EPI_MUL_GELU_GRAD, aux=z.to(d)).cpu()
     np.testing.assert_allclose(got.numpy(), (refd * zz.grad).float().numpy(), **tol)
+
+
+@pytest.mark.parametrize("mode", ["exact", "split", "bf16"])
+def test_gemm_fuzz_shapes_all_layouts(ops, mode):
+    """Seeded sweep over awkward shapes (edges that are not tile multiples, tiny N / M, K a multiple of 16 -> guard-free FAST loop with
+    clamped rows; K not a multiple of 16 or unaligned leading dimensions -> guarded loop) for the three layouts, against fp64."""
+    rng = np.random.default_rng(1234)
+    d = _dev()
+    ops.set_gemm_mode({"exact": ops.GEMM_EXACT, "split": ops.GEMM_SPLIT, "bf16": ops.GEMM_BF16}[mode])
+    try:
+        _gemm_fuzz_body(ops, rng, d, mode)
+    finally:
+        ops.set_gemm_mode(ops.GEMM_EXACT)
+
+
+def _gemm_fuzz_body(ops, rng, d, mode):
+    for case in range(36):
+        M = int(rng.choice([1, 3, 4, 5, 31, 33, 64, 65, 127, 129, 200, 257, 300]))
+        N = int(rng.choice([1, 2, 4, 7, 8, 36, 63, 64, 65, 100, 129, 192]))
+        K = int(rng.choice([16, 32, 48, 64, 96, 112, 160, 20, 50, 147]))
+        layout = case % 3
+        g = torch.Generator().manual_seed(case)
+        a = torch.randn(M, K, generator=g)
+        b = torch.randn(N, K, generator=g)
+        ref = (a.double() @ b.double().t()).float().numpy()
+        tol = dict(rtol=2e-4, atol=2e-4) if mode != "bf16" else dict(rtol=3e-2, atol=0.05 * math.sqrt(K))
+        if layout == 0:       # NT: y = a @ b^T
+            bias = torch.randn(N, generator=g)
+            got = ops.linear_fwd(a.to(d), b.to(d), bias.to(d)).cpu().numpy()
+            np.testing.assert_allclose(got, ref + bias.numpy(), err_msg=f"NT {M}x{N}x{K}", **tol)
+        elif layout == 1:     # NN: dx[M,N] = a[M,K] @ w[K,N]
+            w = b.t().contiguous()
+            got = ops.linear_dgrad(a.to(d), w.to(d)).cpu().numpy()
+            np.testing.assert_allclose(got, ref, err_msg=f"NN {M}x{N}x{K}", **tol)
+        else:                 # TN: dW[M,N] = dy[K,M]^T @ x[K,N]  (+ fused bias gradient)
+            dy, x = a.t().contiguous(), b.t().contiguous()
+            dW = torch.empty(M, N, device=d)
+            db = torch.empty(M, device=d)
+            ops.linear_wgrad(dy.to(d), x.to(d), dW, db=db)
+            np.testing.assert_allclose(dW.cpu().numpy(), ref, err_msg=f"TN {M}x{N}x{K}", **tol)
+            np.testing.assert_allclose(db.cpu().numpy(), dy.double().sum(0).float().numpy(), rtol=1e-4, atol=1e-4, err_msg=f"TN bias {M}x{K}")
