@@ -239,7 +239,7 @@ def _attn_ref(qkv, B, n, H):
 
 
 @pytest.mark.parametrize("B,n,H", [(2, 197, 6), (3, 99, 3), (2, 59, 2), (2, 17, 2), (1, 5, 3), (2, 138, 6), (1, 577, 2),
-                                   (2, 32, 1), (1, 129, 1), (1, 1, 1)])
+                                   (2, 32, 1), (1, 129, 1), (1, 1, 1), (1, 33, 1), (1, 40, 2), (2, 41, 1), (1, 49, 1), (1, 57, 1), (1, 72, 1)])
 def test_attention_fwd_bwd(ops, B, n, H):
     qkv = _rand("aq", (B * n, 3 * H * 64), 1.0, seed=n)
     qr = qkv.clone().requires_grad_(True)
