@@ -224,17 +224,18 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 1) void gemm_f3
             constexpr int NL = BM / 64 + BN / 64, NP = BK / 2, DSR = (MT + 1) / 2 + (NT + 1) / 2;
             if constexpr (BM == 128 && BN == 128) {
 #pragma unroll
-                for (int i = 0; i < NL; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, NP * MT * NT / NL, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                   // VMEM read
+                for (int i = 0; i < NL; ++i) {                                           // loads in the FIRST half of the MFMAs:
+                    __builtin_amdgcn_sched_group_barrier(0x008, NP * MT * NT / (2 * NL), 0);  // the last one still has half a
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                        // K-step of MFMAs to land under
                 }
+                __builtin_amdgcn_sched_group_barrier(0x008, NP * MT * NT / 2, 0);
             } else {
                 __builtin_amdgcn_sched_group_barrier(0x100, DSR, 0);                     // DS read: pair 0
 #pragma unroll
                 for (int sp = 0; sp < NP; ++sp) {
                     if (sp + 1 < NP) __builtin_amdgcn_sched_group_barrier(0x100, DSR, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);             // MFMA
-                    if (sp % (NP / NL) == NP / NL - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                    if (sp % (NP / NL) == NP / NL - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (spread: early placement measured -2 % here, +2 % on 128x128)
                 }
             }
         }
