@@ -309,3 +309,24 @@ def test_split_gemm_mode_keeps_fp32_parity(name):
     params = dict(student.named_parameters())
     for n, ref_norm in zip([str(s) for s in g["grad_names"]], g["grad_norms"]):
         np.testing.assert_allclose(float(params[n].grad.double().norm()), ref_norm, rtol=1e-3, atol=1e-6, err_msg=n)
+
+
+def test_overfit_one_batch():
+    """The reference's only (commented-out) check is 'overfit one batch' (train.py:22-25).  Same idea on the accelerated step: repeated
+    optimiser steps on one fixed batch must drive both loss terms down - end-to-end evidence that gradients, AdamW, the parameter
+    groups and the LR schedule act together (micro1 geometry, 60 steps)."""
+    from d2s.engine import TrainStep
+    dev = torch.device("cuda:0")
+    case = cases.MODEL_CASES["micro1"]
+    student, teacher, _, _ = build_models(case, dev)
+    ts = TrainStep(student, teacher, make_args(case["cfg"]), lr=2e-3, min_lr=1e-5, weight_decay=0.0, epochs=1000, warmup_steps=0)
+    x, y = _t(cases.make_images(case)).to(dev), _t(cases.make_labels(case)).to(dev)
+    first = last = None
+    for i in range(60):
+        info = ts(x, y)
+        cur = (float(info["mask_loss"].detach()), float(info["backbone_loss"].detach()))
+        first = first or cur
+        last = cur
+    assert np.isfinite(last).all()
+    assert last[0] < 0.5 * first[0], (first, last)
+    assert last[1] < 0.9 * first[1], (first, last)
