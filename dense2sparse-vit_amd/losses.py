@@ -4,7 +4,7 @@
 Differences that are deliberate and documented:
   * running statistics stay on the device (no .item() per step, losses.py:111,230-233 force a D2H sync every step);
     metrics values are 0-d tensors, `float(v)` reads them.
-  * only the kl_div mask loss and hard-label cross entropy (mixup off) are on the accelerated path; the reference's bce
+  * the kl_div and mse mask losses and hard-label cross entropy (mixup off) are on the accelerated path; the reference's bce
     branch is broken as written (undefined `args` / `self.mask_criterions`, losses.py:57-58).
 """
 import torch
@@ -19,8 +19,9 @@ class MaskLoss(torch.nn.Module):
         self.phase = phase
         self.keep_ratios = args.keep_ratios
         self.loss_type = args.mask_loss_type
-        if self.loss_type != "kl_div":
-            raise NotImplementedError("only mask_loss_type='kl_div' is on the accelerated hot path (losses.py:75-96)")
+        if self.loss_type not in ("kl_div", "mse"):
+            raise NotImplementedError("mask_loss_type 'kl_div' (losses.py:75-96) and 'mse' (:61-73) are on the accelerated path; the "
+                                      "reference's 'bce' branch is broken as written (:57-58)")
         self.count = 1
         self.running_loss = 0
         self.runnings_accs = [0 for _ in self.keep_ratios]
@@ -40,6 +41,9 @@ class MaskLoss(torch.nn.Module):
                 gt_vals = target
             T = gt_vals.shape[1]
             nk = int(T * ratio)                                                               # :132,154
+            if self.loss_type == "mse":      # :61-73: 100 * mean squared difference between the raw scores and the target; no accuracy
+                mask_loss = mask_loss + DF.RowLossFn.apply(pred_logits[i], ops.MSE_TARGET, target, None, None, B * T / 100.0)
+                continue
             with torch.no_grad():
                 gt_ids, _ = ops.select_topk(gt_vals, nk)
                 pm_ids, _ = ops.select_topk(ops.softmax_rows(pred_logits[i].detach().contiguous()), nk)

@@ -41,8 +41,8 @@ def check_supported(args):
         bad.append("--early-exit")
     if args.random_drop:
         bad.append("--random-drop")
-    if args.mask_loss_type != "kl_div":
-        bad.append(f"--mask-loss-type {args.mask_loss_type} (only kl_div is on the path)")
+    if args.mask_loss_type not in ("kl_div", "mse"):
+        bad.append(f"--mask-loss-type {args.mask_loss_type} (kl_div and mse are on the path; bce is broken in the reference)")
     if args.use_dp:
         bad.append("--use-dp (one process per GPU only: --use-ddp under torch.distributed.run)")
     if bad:

@@ -302,6 +302,19 @@ def mask_loss_kl(pred_logits, cls_attn, kept, keep_ratios):
     return loss, accs
 
 
+def mask_loss_mse(pred_logits, cls_attn, kept):
+    """MaskLoss.forward, mse branch, losses.py:61-73: 100 * mse(raw scores, renormalised teacher target) per stage; the target of
+    stage i > 0 is re-gathered by kept_{i-1} and renormalised.  (The reference accumulates no mask accuracy in this branch.)"""
+    target = teacher_target(cls_attn)
+    loss = 0
+    for i in range(len(kept)):
+        if i > 0:
+            target = torch.gather(target, 1, kept[i - 1])
+            target = target / torch.sum(target, dim=1, keepdim=True)
+        loss = loss + 100 * F.mse_loss(pred_logits[i], target, reduction="mean")
+    return loss
+
+
 def backbone_loss(logits_s, token_s, logits_t, token_t, kept, labels):
     """BackboneLoss.forward, losses.py:185-227 (mixup off -> CrossEntropyLoss, :174).  The teacher tokens
     are gathered with the LAST stage's (stage-relative) ids exactly as the reference does (:212).

@@ -69,3 +69,22 @@ def test_mask_predictor_cli_runs_the_epoch_loop(capsys):
     out = capsys.readouterr().out
     assert 0.0 <= best <= 1.0
     assert "Epoch 2/2" in out and "Training complete" in out and "train images/s" in out
+
+
+def test_mask_loss_mse_branch_matches_reference_fixture():
+    """losses.MaskLoss(mask_loss_type='mse') on the HIP path (d2s_kl_rows mode 3 + d2s_gather_renorm) against the reference's own
+    output: loss, gradients of both stages' scores, and the metrics keys it writes."""
+    from losses import MaskLoss
+    dev = torch.device("cuda:0")
+    g = cases.load_golden("mask_loss_mse")
+    p0 = torch.from_numpy(g["p0"]).to(dev).requires_grad_(True)
+    p1 = torch.from_numpy(g["p1"]).to(dev).requires_grad_(True)
+    args = types.SimpleNamespace(keep_ratios=[0.7, 0.35], mask_loss_type="mse")
+    metrics = {}
+    loss = MaskLoss(args, "train")([p0, p1], torch.from_numpy(g["cls_attn"]).to(dev),
+                                   [torch.from_numpy(g["kept0"]).to(dev), torch.from_numpy(g["kept1"]).to(dev)], metrics)
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=2e-5)
+    np.testing.assert_allclose(p0.grad.cpu().numpy(), g["g0"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(p1.grad.cpu().numpy(), g["g1"], rtol=1e-4, atol=1e-7)
+    assert sorted(metrics) == [str(k) for k in g["metric_keys"]]

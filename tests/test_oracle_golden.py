@@ -147,3 +147,15 @@ def test_keep_counts_truncate_like_reference():
     assert O.keep_counts(cfg) == [137, 98, 58]       # dynamic_vit.py:852 int() truncation
     cfg384 = O.make_cfg(img_size=384, dim=768, heads=12, pruning_loc=(3,), token_ratio=(0.3,))
     assert O.keep_counts(cfg384) == [58]              # hard-coded init_n = 196 quirk (:828)
+
+
+def test_mask_loss_mse_matches_reference_fixture():
+    """oracle.mask_loss_mse vs the reference's MaskLoss(mask_loss_type='mse') output (loss and gradients w.r.t. both stages' scores)."""
+    g = cases.load_golden("mask_loss_mse")
+    p0 = torch.from_numpy(g["p0"]).requires_grad_(True)
+    p1 = torch.from_numpy(g["p1"]).requires_grad_(True)
+    loss = O.mask_loss_mse([p0, p1], torch.from_numpy(g["cls_attn"]), [torch.from_numpy(g["kept0"]), torch.from_numpy(g["kept1"])])
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-6)
+    np.testing.assert_allclose(p0.grad.numpy(), g["g0"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(p1.grad.numpy(), g["g1"], rtol=1e-5, atol=1e-8)

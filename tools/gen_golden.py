@@ -324,6 +324,29 @@ def gen_t2t():
     print(f"[golden] t2t: {len(out)} arrays")
 
 
+def gen_mask_loss_mse(losses):
+    """MaskLoss with mask_loss_type='mse' (losses.py:61-73) at loss level: synthetic scores / teacher CLS-attention rows / kept ids in,
+    loss and d loss / d scores out (two stages, so that the re-gather + renormalisation of the target is covered)."""
+    B, L, H, N = 3, 4, 2, 16
+    k0, k1 = 11, 5
+    normal = lambda name, shape, std: synth.normal(name, shape, std=std, seed=13)
+    cls_attn = torch.softmax(_t(normal("mse/cls", (B, L, H, N + 1), 1.0)), dim=-1)
+    p0 = _t(normal("mse/p0", (B, N), 0.5)).requires_grad_(True)
+    p1 = _t(normal("mse/p1", (B, k0), 0.5)).requires_grad_(True)
+    g = torch.Generator().manual_seed(5)
+    kept0 = torch.stack([torch.randperm(N, generator=g)[:k0].sort().values for _ in range(B)])
+    kept1 = torch.stack([torch.randperm(k0, generator=g)[:k1].sort().values for _ in range(B)])
+    args = _Args()
+    args.keep_ratios, args.mask_loss_type = [0.7, 0.35], "mse"
+    fn = losses.MaskLoss(args, "train")
+    metrics = {}
+    loss = fn([p0, p1], cls_attn, [kept0, kept1], metrics)
+    loss.backward()
+    np.savez_compressed(os.path.join(OUT, "mask_loss_mse.npz"), cls_attn=_np(cls_attn), p0=_np(p0), p1=_np(p1), kept0=_np(kept0), kept1=_np(kept1),
+                        loss=_np(loss), g0=_np(p0.grad), g1=_np(p1.grad), metric_keys=np.array(sorted(metrics)))
+    print("mask_loss_mse.npz loss", float(loss), sorted(metrics))
+
+
 def gen_checkpoint_ingestion(dv):
     """checkpoint_filter_fn / resize_pos_embed of the reference (dynamic_vit.py:1178-1213) on a synthetic DeiT-style checkpoint: a
     {'model': ...} wrapper, a patch projection stored as a matrix, and a 4x4-grid position table loaded into a 6x6-grid model."""
@@ -348,6 +371,7 @@ def main():
     gen_micro_intermediates(dv)
     gen_t2t()
     gen_checkpoint_ingestion(dv)
+    gen_mask_loss_mse(losses)
     for name in cases.MODEL_CASES:
         gen_model_case(dv, losses, name)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
