@@ -119,6 +119,30 @@ def layernorm_bwd(x, rowmap, dy, w, mean, rstd, dx, add_src, dw, db, rows, D, ac
     return dx
 
 
+def batchnorm_fwd(x, w, b, running_mean, running_var, training, eps=1e-5, momentum=0.1):
+    """BatchNorm1d over the rows of x [R, C] (dynamic_vit.py:350-367).  Returns (y, mean, rstd); updates the running estimates in
+    place when training."""
+    _f32(x)
+    R, C = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+    ws = workspace(lib.query("d2s_batchnorm_workspace_bytes", R, C), x.device)
+    lib.call("d2s_batchnorm_fwd", lib.ptr(x), lib.ptr(w), lib.ptr(b), lib.ptr(y), lib.ptr(mean), lib.ptr(rstd), lib.ptr(running_mean),
+             lib.ptr(running_var), R, C, float(eps), float(momentum), int(bool(training)), lib.ptr(ws), ws.numel())
+    return y, mean, rstd
+
+
+def batchnorm_bwd(x, dy, w, mean, rstd, dw, db, training, relu_mask=False, accumulate=False):
+    _f32(x), _f32(dy)
+    R, C = x.shape
+    dx = torch.empty_like(x)
+    ws = workspace(lib.query("d2s_batchnorm_workspace_bytes", R, C), x.device)
+    lib.call("d2s_batchnorm_bwd", lib.ptr(x), lib.ptr(dy), lib.ptr(w), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dx), lib.ptr(dw), lib.ptr(db),
+             int(relu_mask), int(accumulate), int(bool(training)), R, C, lib.ptr(ws), ws.numel())
+    return dx
+
+
 def softmax_rows(scores):
     _f32(scores)
     R, T = scores.shape

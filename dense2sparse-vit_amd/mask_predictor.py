@@ -33,8 +33,8 @@ _TEACHERS = {"deit_tiny": "dynamic_vit_tiny_patch16_224_teacher", "deit_small": 
 def check_supported(args):
     """Flags whose code path is outside the accelerated hot path fail here, loudly, instead of silently training something else."""
     bad = []
-    if args.predictor_bn:
-        bad.append("--predictor-bn (per-rank batch statistics; SURVEY 8e caveat i)")
+    if args.predictor_bn and args.small_predictor:
+        bad.append("--predictor-bn together with --small-predictor (only the large BatchNorm predictor is on the path)")
     if args.patch_score_threshold is not None:
         bad.append("--patch-score-threshold (broken in the reference: dynamic_vit.py:936, losses.py:216-218)")
     if args.early_exit:
@@ -47,6 +47,8 @@ def check_supported(args):
         bad.append("--use-dp (one process per GPU only: --use-ddp under torch.distributed.run)")
     if bad:
         raise SystemExit("not on the accelerated path: " + "; ".join(bad))
+    if args.predictor_bn and args.use_ddp:
+        print("Attention: --predictor-bn keeps per-rank batch statistics (not synchronised), exactly like the reference")
     if args.mixup > 0 or args.cutmix > 0 or args.cutmix_minmax is not None:
         print("Attention: mixup/cutmix are not used (synthetic batches)")
     args.mixup, args.cutmix, args.cutmix_minmax = 0.0, 0.0, None

@@ -134,14 +134,24 @@ class PatchEmbed(nn.Module):
 
 
 class BatchNormLayer(nn.Module):
-    """:350-367 (predictor_bn variant).  Parameter container only: the BN predictor is outside the accelerated path."""
+    """:350-367: BatchNorm1d over all B * N token rows of a [B, N, D] tensor (the reference transposes around nn.BatchNorm1d).  Holds
+    the parameters / running estimates under the reference's keys (`bn.weight`, `bn.running_mean`, ...); inside the predictor the
+    arithmetic runs in d2s.functional_bn.PredictorBNFn, standalone use goes through the same kernels."""
 
     def __init__(self, input_dim=384):
         super().__init__()
         self.bn = nn.BatchNorm1d(input_dim)
 
     def forward(self, x):
-        raise NotImplementedError("--predictor-bn is not on the accelerated hot path (SURVEY 8f.4)")
+        from d2s import ops
+        B, N, D = x.shape
+        if torch.is_grad_enabled() and (x.requires_grad or self.bn.weight.requires_grad):
+            raise NotImplementedError("differentiable standalone BatchNormLayer: use it through PredictorLG (predictor_bn=True)")
+        y, _, _ = ops.batchnorm_fwd(x.contiguous().view(B * N, D), self.bn.weight, self.bn.bias, self.bn.running_mean,
+                                    self.bn.running_var, self.training, eps=self.bn.eps, momentum=self.bn.momentum)
+        if self.training:
+            self.bn.num_batches_tracked += 1
+        return y.view(B, N, D)
 
 
 class PredictorLG(nn.Module):
@@ -149,11 +159,21 @@ class PredictorLG(nn.Module):
 
     def __init__(self, embed_dim=384, topk_selection=False, k=None, small_predictor=False, loss_type="kl_div", use_bn=False):
         super().__init__()
-        if use_bn:
-            raise NotImplementedError("--predictor-bn is not on the accelerated hot path (SURVEY 8f.4)")
-        self.small_predictor, self.k, self.topk_selection, self.loss_type = small_predictor, k, topk_selection, loss_type
+        if use_bn and small_predictor:
+            raise NotImplementedError("the small BatchNorm predictor (:383-400) is not on the accelerated path; the large one (:438-476) is")
+        self.small_predictor, self.k, self.topk_selection, self.loss_type, self.use_bn = small_predictor, k, topk_selection, loss_type, use_bn
         D = embed_dim
         relu = nn.ReLU()
+        if use_bn:               # :438-476: the large predictor with BatchNormLayer in place of every LayerNorm
+            self.in_conv = nn.Sequential(BatchNormLayer(D), nn.Linear(D, D * 4), relu)
+            self.out_conv = nn.Sequential(
+                BatchNormLayer(D * 4), nn.Linear(D * 4, D * 2), relu,
+                BatchNormLayer(D * 2), nn.Linear(D * 2, D), relu,
+                BatchNormLayer(D), nn.Linear(D, D // 2), relu,
+                BatchNormLayer(D // 2), nn.Linear(D // 2, D // 4), relu,
+                BatchNormLayer(D // 4), nn.Linear(D // 4, 1), nn.Flatten(start_dim=-2, end_dim=-1))
+            self.topk = PerturbedTopK(k)
+            return
         if small_predictor:      # :409-426 (LayerNorm + GELU variant)
             self.in_conv = nn.Sequential(nn.LayerNorm(D), nn.Linear(D, D), nn.GELU())
             self.out_conv = nn.Sequential(nn.LayerNorm(D), nn.Linear(D, D // 2), nn.GELU(), nn.LayerNorm(D // 2),
@@ -171,10 +191,14 @@ class PredictorLG(nn.Module):
         self.topk = PerturbedTopK(k)
 
     def _params(self):
-        ps = [self.in_conv[0].weight, self.in_conv[0].bias, self.in_conv[1].weight, self.in_conv[1].bias]
+        norm = (lambda m: m.bn) if self.use_bn else (lambda m: m)
+        ps = [norm(self.in_conv[0]).weight, norm(self.in_conv[0]).bias, self.in_conv[1].weight, self.in_conv[1].bias]
         for i in ((0, 3, 6) if self.small_predictor else (0, 3, 6, 9, 12)):
-            ps += [self.out_conv[i].weight, self.out_conv[i].bias, self.out_conv[i + 1].weight, self.out_conv[i + 1].bias]
+            ps += [norm(self.out_conv[i]).weight, norm(self.out_conv[i]).bias, self.out_conv[i + 1].weight, self.out_conv[i + 1].bias]
         return ps
+
+    def _bn_layers(self):
+        return [self.in_conv[0].bn] + [self.out_conv[i].bn for i in (0, 3, 6, 9, 12)]
 
     def forward_tokens(self, x_with_cls):
         """Scores for x[:, 1:] of a [B, n, D] tensor, read in place (no slice copy).  -> (scores, keep_probs)."""
@@ -182,6 +206,15 @@ class PredictorLG(nn.Module):
             return None  # the reference's forward falls through and returns None (:537)
         if self.loss_type not in ("kl_div", "mse"):
             raise NotImplementedError("sigmoid scores (bce loss type) are not on the accelerated hot path")
+        if self.use_bn:
+            from d2s.functional_bn import PredictorBNFn
+            bns = self._bn_layers()
+            running = [t for bn in bns for t in (bn.running_mean, bn.running_var)]
+            out = PredictorBNFn.apply(x_with_cls, self.training, running, *self._params())
+            if self.training:
+                for bn in bns:
+                    bn.num_batches_tracked += 1
+            return out
         if self.small_predictor:
             from d2s.functional_small import SmallPredictorFn
             return SmallPredictorFn.apply(x_with_cls, *self._params())

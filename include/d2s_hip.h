@@ -145,6 +145,18 @@ int d2s_scale_by_scalar(const float* x, const float* gscalar, float scale, float
 int d2s_mask_agreement(const long long* ids_a, const long long* ids_b, int B, int T, int k, float* agree, d2s_stream_t stream);
 int d2s_act_grad(const float* g, const float* z, float* out, long n, int kind, d2s_stream_t stream);
 
+/* ---- BatchNorm1d over the token rows of [R, C] (the --predictor-bn variant: vit_models/dynamic_vit.py:350-367 BatchNormLayer) ------ */
+size_t d2s_batchnorm_workspace_bytes(long R, int C);
+/* training != 0: batch statistics (saved to mean / rstd; running estimates updated with `momentum`, unbiased variance, when given);
+ * training == 0: the running estimates are used (and copied into mean / rstd for the backward). */
+int d2s_batchnorm_fwd(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd, float* running_mean,
+                      float* running_var, long R, int C, float eps, float momentum, int training, void* workspace,
+                      size_t workspace_bytes, d2s_stream_t stream);
+/* dx always; dw / db (+)= when given; relu_mask != 0 zeroes dx where x <= 0 (a ReLU whose output is this layer's input). */
+int d2s_batchnorm_bwd(const float* x, const float* dy, const float* w, const float* mean, const float* rstd, float* dx, float* dw,
+                      float* db, int relu_mask, int accumulate, int training, long R, int C, void* workspace, size_t workspace_bytes,
+                      d2s_stream_t stream);
+
 /* ---- optimiser: torch.optim.AdamW (mask_predictor.py:229-230) over a flat arena, one launch ------------------------ */
 int d2s_adamw_chunk_elems(void);
 int d2s_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const void* chunk_desc, int n_chunks,

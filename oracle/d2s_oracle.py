@@ -25,7 +25,7 @@ import torch.nn.functional as F
 # --------------------------------------------------------------------------------------------------
 def make_cfg(img_size=224, patch=16, dim=384, depth=12, heads=6, mlp_ratio=4.0, num_classes=1000,
              pruning_loc=(), token_ratio=(), small_predictor=False, loss_type="kl_div", init_n=None,
-             ln_eps=1e-6):
+             ln_eps=1e-6, predictor_bn=False):
     """Geometry of one student/teacher pair.  `init_n` reproduces the reference's hard-coded
     `init_n = 14 * 14` (vit_models/dynamic_vit.py:828,852) when left at None for 224x224 inputs; the
     keep count is always int(init_n * ratio) like the reference."""
@@ -33,7 +33,7 @@ def make_cfg(img_size=224, patch=16, dim=384, depth=12, heads=6, mlp_ratio=4.0, 
     return dict(img_size=img_size, patch=patch, dim=dim, depth=depth, heads=heads, mlp_ratio=mlp_ratio,
                 num_classes=num_classes, pruning_loc=tuple(pruning_loc), token_ratio=tuple(token_ratio),
                 small_predictor=small_predictor, loss_type=loss_type, n_patches=n_patches,
-                init_n=(14 * 14 if init_n is None else init_n), ln_eps=ln_eps)
+                init_n=(14 * 14 if init_n is None else init_n), ln_eps=ln_eps, predictor_bn=predictor_bn)
 
 
 def keep_counts(cfg):
@@ -57,6 +57,7 @@ def student_param_shapes(cfg):
                 (p + "mlp.fc1.weight", (hid, D)), (p + "mlp.fc1.bias", (hid,)),
                 (p + "mlp.fc2.weight", (D, hid)), (p + "mlp.fc2.bias", (D,))]
     out += [("norm.weight", (D,)), ("norm.bias", (D,)), ("head.weight", (C, D)), ("head.bias", (C,))]
+    bn = "bn." if cfg.get("predictor_bn") else ""      # BatchNormLayer wraps nn.BatchNorm1d as `.bn` (:350-367)
     for s in range(len(cfg["pruning_loc"])):
         p = f"score_predictor.{s}."
         if cfg["small_predictor"]:
@@ -65,13 +66,13 @@ def student_param_shapes(cfg):
             widths = [D, D // 2, D // 4, 1]
             idx = [0, 1, 3, 4, 6, 7]
         else:
-            out += [(p + "in_conv.0.weight", (D,)), (p + "in_conv.0.bias", (D,)),
+            out += [(p + f"in_conv.0.{bn}weight", (D,)), (p + f"in_conv.0.{bn}bias", (D,)),
                     (p + "in_conv.1.weight", (4 * D, D)), (p + "in_conv.1.bias", (4 * D,))]
             widths = [4 * D, 2 * D, D, D // 2, D // 4, 1]
             idx = [0, 1, 3, 4, 6, 7, 9, 10, 12, 13]
         for j in range(len(widths) - 1):
             ln_i, fc_i = idx[2 * j], idx[2 * j + 1]
-            out += [(p + f"out_conv.{ln_i}.weight", (widths[j],)), (p + f"out_conv.{ln_i}.bias", (widths[j],)),
+            out += [(p + f"out_conv.{ln_i}.{bn}weight", (widths[j],)), (p + f"out_conv.{ln_i}.{bn}bias", (widths[j],)),
                     (p + f"out_conv.{fc_i}.weight", (widths[j + 1], widths[j])),
                     (p + f"out_conv.{fc_i}.bias", (widths[j + 1],))]
     return out
@@ -143,15 +144,30 @@ def block(sd, i, x, cfg, policy=None):
     return x, cls_row
 
 
-def predictor(sd, s, x, cfg, margins=None):
+def predictor(sd, s, x, cfg, margins=None, training=True, bn_state=None):
     """PredictorLG.forward with topk_selection=True, vit_models/dynamic_vit.py:536-560.
-    Large LN variant :491-531 (ReLU), small LN variant :409-426 (GELU).  nn.LayerNorm default eps 1e-5.
-    Returns (scores, keep_probs) each [B, n-1]."""
+    Large LN variant :491-531 (ReLU), small LN variant :409-426 (GELU), large BatchNorm variant :438-476 (predictor_bn: every
+    LayerNorm replaced by BatchNormLayer :350-367 = BatchNorm1d over all B * N rows; `bn_state` maps "<key>running_mean/var" to the
+    running estimates, updated in place in training mode; missing entries start at 0 / 1 like a fresh module).
+    nn.LayerNorm / nn.BatchNorm1d default eps 1e-5.  Returns (scores, keep_probs) each [B, n-1]."""
     p = f"score_predictor.{s}."
     small = cfg["small_predictor"]
     act = F.gelu if small else F.relu
     D = cfg["dim"]
-    h = F.layer_norm(x, (D,), sd[p + "in_conv.0.weight"], sd[p + "in_conv.0.bias"], 1e-5)
+    use_bn = bool(cfg.get("predictor_bn"))
+
+    def norm(h, key):
+        if not use_bn:
+            w = sd[key + "weight"]
+            return F.layer_norm(h, (w.shape[0],), w, sd[key + "bias"], 1e-5)
+        w = sd[key + "bn.weight"]
+        st = bn_state if bn_state is not None else {}
+        rm = st.setdefault(key + "bn.running_mean", torch.zeros_like(w.detach()))
+        rv = st.setdefault(key + "bn.running_var", torch.ones_like(w.detach()))
+        Bh, Nh, Ch = h.shape
+        return F.batch_norm(h.reshape(Bh * Nh, Ch), rm, rv, w, sd[key + "bn.bias"], training, 0.1, 1e-5).reshape(Bh, Nh, Ch)
+
+    h = norm(x, p + "in_conv.0.")
     z = F.linear(h, sd[p + "in_conv.1.weight"], sd[p + "in_conv.1.bias"])
     if margins is not None:
         margins.append(float(z.detach().abs().min()))
@@ -164,8 +180,7 @@ def predictor(sd, s, x, cfg, margins=None):
     nl = len(idx) // 2
     for j in range(nl):
         ln_i, fc_i = idx[2 * j], idx[2 * j + 1]
-        w = sd[p + f"out_conv.{ln_i}.weight"]
-        h = F.layer_norm(h, (w.shape[0],), w, sd[p + f"out_conv.{ln_i}.bias"], 1e-5)
+        h = norm(h, p + f"out_conv.{ln_i}.")
         h = F.linear(h, sd[p + f"out_conv.{fc_i}.weight"], sd[p + f"out_conv.{fc_i}.bias"])
         if j < nl - 1:
             if margins is not None:
@@ -219,10 +234,11 @@ def batch_index_select(x, idx):
 # --------------------------------------------------------------------------------------------------
 # models
 # --------------------------------------------------------------------------------------------------
-def student_forward(sd, x, cfg, training=True):
+def student_forward(sd, x, cfg, training=True, bn_state=None):
     """VisionTransformerDiffPruning.forward, vit_models/dynamic_vit.py:814-1015 (patch_score_threshold
     None).  training: (logits, features, [pred_logits], [kept]); eval: (logits, [cls_attn], [pred_logits],
-    [kept]).  Also returns aux = dict(dropped=[...], keep_probs=[...], cls_attns=[...])."""
+    [kept]).  Also returns aux = dict(dropped=[...], keep_probs=[...], cls_attns=[...]).  bn_state: running estimates of a
+    predictor_bn student (see predictor)."""
     x = embed_tokens(sd, x, cfg)
     counts = keep_counts(cfg)
     pred_logits, kept_all, dropped_all, probs_all, cls_attns = [], [], [], [], []
@@ -230,7 +246,7 @@ def student_forward(sd, x, cfg, training=True):
     stage = 0           # gradient below it) is decided by rounding, which parity tests have to know about
     for i in range(cfg["depth"]):
         if i in cfg["pruning_loc"]:
-            scores, probs = predictor(sd, stage, x[:, 1:], cfg, relu_margins)
+            scores, probs = predictor(sd, stage, x[:, 1:], cfg, relu_margins, training=training, bn_state=bn_state)
             kept, dropped = select_topk(probs, counts[stage])
             pred_logits.append(scores)
             kept_all.append(kept)

@@ -420,3 +420,33 @@ def _gemm_fuzz_body(ops, rng, d, mode):
             ops.linear_wgrad(dy.to(d), x.to(d), dW, db=db)
             np.testing.assert_allclose(dW.cpu().numpy(), ref, err_msg=f"TN {M}x{N}x{K}", **tol)
             np.testing.assert_allclose(db.cpu().numpy(), dy.double().sum(0).float().numpy(), rtol=1e-4, atol=1e-4, err_msg=f"TN bias {M}x{K}")
+
+
+@pytest.mark.parametrize("R,C,training", [(4 * 16, 128, True), (128 * 5, 96, True), (777, 384, True), (300, 64, False), (2 * 196, 1536, True)])
+def test_batchnorm_fwd_bwd(ops, R, C, training):
+    """d2s_batchnorm_fwd / bwd (the --predictor-bn BatchNormLayer, dynamic_vit.py:350-367) against torch's batch_norm on the same rows:
+    output, saved statistics, running estimates after the update, dx (with and without the ReLU-output mask), dw, db."""
+    g = torch.Generator().manual_seed(R + C)
+    x = torch.randn(R, C, generator=g) * 1.7 + 0.4
+    w = 1 + 0.3 * torch.randn(C, generator=g)
+    b = 0.2 * torch.randn(C, generator=g)
+    dy = torch.randn(R, C, generator=g)
+    rm0, rv0 = 0.1 * torch.randn(C, generator=g), 1 + 0.2 * torch.rand(C, generator=g)
+    xr = x.clone().double().requires_grad_(True)
+    wr, br = w.clone().double().requires_grad_(True), b.clone().double().requires_grad_(True)
+    rm, rv = rm0.clone().double(), rv0.clone().double()
+    yr = torch.nn.functional.batch_norm(xr, rm, rv, wr, br, training=training, momentum=0.1, eps=1e-5)
+    yr.backward(dy.double())
+    d = _dev()
+    rmd, rvd = rm0.to(d), rv0.to(d)
+    y, mean, rstd = ops.batchnorm_fwd(x.to(d), w.to(d), b.to(d), rmd, rvd, training)
+    np.testing.assert_allclose(y.cpu().numpy(), yr.detach().float().numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(rmd.cpu().numpy(), rm.float().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rvd.cpu().numpy(), rv.float().numpy(), rtol=1e-5, atol=1e-6)
+    dw, db = torch.empty(C, device=d), torch.empty(C, device=d)
+    dx = ops.batchnorm_bwd(x.to(d), dy.to(d), w.to(d), mean, rstd, dw, db, training)
+    np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.float().numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dw.cpu().numpy(), wr.grad.float().numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), br.grad.float().numpy(), rtol=2e-4, atol=2e-4)
+    dxm = ops.batchnorm_bwd(x.to(d), dy.to(d), w.to(d), mean, rstd, None, None, training, relu_mask=True)
+    np.testing.assert_allclose(dxm.cpu().numpy(), (xr.grad.float() * (x > 0)).numpy(), rtol=2e-4, atol=2e-5)

@@ -33,10 +33,13 @@ def build_models(case, device):
                   num_heads=cfg["heads"], mlp_ratio=cfg["mlp_ratio"], qkv_bias=True, num_classes=cfg["num_classes"])
     student = vit_models.VisionTransformerDiffPruning(pruning_loc=list(cfg["pruning_loc"]), token_ratio=list(cfg["token_ratio"]),
                                                       distill=True, topk_selection=True, predictor_loss_type=cfg["loss_type"],
-                                                      small_predictor=cfg["small_predictor"], **common)
+                                                      small_predictor=cfg["small_predictor"], predictor_bn=bool(cfg.get("predictor_bn")),
+                                                      **common)
     teacher = vit_models.VisionTransformerTeacher(**common)
     sd_s, sd_t = cases.make_weights(case)
-    student.load_state_dict({k: _t(v) for k, v in sd_s.items()}, strict=True)
+    own = student.state_dict()
+    buffers = {k: own[k] for k in own if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}   # fresh BatchNorm buffers
+    student.load_state_dict({**buffers, **{k: _t(v) for k, v in sd_s.items()}}, strict=True)
     teacher.load_state_dict({k: _t(v) for k, v in sd_t.items()}, strict=True)
     return student.to(device), teacher.to(device), sd_s, sd_t
 
@@ -330,3 +333,27 @@ def test_overfit_one_batch():
     assert np.isfinite(last).all()
     assert last[0] < 0.5 * first[0], (first, last)
     assert last[1] < 0.9 * first[1], (first, last)
+
+
+def test_predictor_bn_running_estimates_and_eval():
+    """--predictor-bn on the HIP path: one training forward updates the running estimates exactly like the reference's nn.BatchNorm1d
+    (fixture buf_*), and the eval forward that uses them reproduces the reference's eval logits and kept ids."""
+    dev = torch.device("cuda:0")
+    case = cases.MODEL_CASES["micro_bn"]
+    g = cases.load_golden("model_micro_bn")
+    student, _, _, _ = build_models(case, dev)
+    x = _t(cases.make_images(case)).to(dev)
+    student.train()
+    with torch.no_grad():
+        student(x)
+    for k, v in student.state_dict().items():
+        if k.endswith(("running_mean", "running_var")):
+            np.testing.assert_allclose(v.cpu().numpy(), g["buf_" + k], rtol=1e-4, atol=1e-6, err_msg=k)
+        elif k.endswith("num_batches_tracked"):
+            assert int(v) == int(g["buf_" + k]), k
+    student.eval()
+    with torch.no_grad():
+        logits, cls_attns, pred_logits, kept = student(x)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["eval_logits"], rtol=1e-4, atol=2e-5)
+    for i, k in enumerate(kept):
+        np.testing.assert_array_equal(k.cpu().numpy(), g[f"eval_kept_{i}"])

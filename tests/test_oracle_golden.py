@@ -57,7 +57,9 @@ def test_train_step_matches_reference(name):
             continue
         assert p.grad is not None, n
         gf = p.grad.flatten()
-        np.testing.assert_allclose(float(gf.double().norm()), ref_norm, rtol=2e-4, atol=1e-9, err_msg=n)
+        # atol: gradients that are zero in exact arithmetic (e.g. the bias in front of the score head: the score gradients of an
+        # image sum to zero) come out as rounding noise ~1e-8 on either side
+        np.testing.assert_allclose(float(gf.double().norm()), ref_norm, rtol=2e-4, atol=5e-8, err_msg=n)
         m = min(8, gf.numel())
         np.testing.assert_allclose(gf[:m].numpy(), ref_head[:m], rtol=2e-3, atol=1e-7, err_msg=n)
 
@@ -159,3 +161,22 @@ def test_mask_loss_mse_matches_reference_fixture():
     np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-6)
     np.testing.assert_allclose(p0.grad.numpy(), g["g0"], rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(p1.grad.numpy(), g["g1"], rtol=1e-5, atol=1e-8)
+
+
+def test_predictor_bn_running_estimates_and_eval_match_reference():
+    """--predictor-bn (micro_bn): after ONE training forward the running estimates equal the reference's, and the eval forward that
+    uses them reproduces the reference's eval logits and kept ids."""
+    case = cases.MODEL_CASES["micro_bn"]
+    g = cases.load_golden("model_micro_bn")
+    sd_s, _ = cases.make_weights(case)
+    sd = _sd(sd_s)
+    x = _t(cases.make_images(case))
+    state = {}
+    with torch.no_grad():
+        O.student_forward(sd, x, case["cfg"], training=True, bn_state=state)
+        for k, v in state.items():
+            np.testing.assert_allclose(v.numpy(), g["buf_" + k], rtol=1e-5, atol=1e-7, err_msg=k)
+        (logits, cls_attns, pred_logits, kept), _ = O.student_forward(sd, x, case["cfg"], training=False, bn_state=state)
+    np.testing.assert_allclose(logits.numpy(), g["eval_logits"], rtol=1e-5, atol=1e-6)
+    for i, k in enumerate(kept):
+        np.testing.assert_array_equal(k.numpy(), g[f"eval_kept_{i}"])

@@ -97,8 +97,9 @@ def _np(t):
 
 def _load_sd(module, sd):
     own = module.state_dict()
-    assert set(own.keys()) == set(sd.keys()), (sorted(set(own) ^ set(sd)))
-    module.load_state_dict({k: _t(v) for k, v in sd.items()}, strict=True)
+    buffers = {k for k in own if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}   # BatchNorm buffers keep their
+    assert set(own.keys()) - buffers == set(sd.keys()), (sorted((set(own) - buffers) ^ set(sd)))          # fresh-module values
+    module.load_state_dict({**{k: own[k] for k in buffers}, **{k: _t(v) for k, v in sd.items()}}, strict=True)
 
 
 class _Args:
@@ -114,7 +115,8 @@ def build_ref_models(dv, case):
             img_size=cfg["img_size"], patch_size=cfg["patch"], embed_dim=cfg["dim"], depth=cfg["depth"],
             num_heads=cfg["heads"], mlp_ratio=cfg["mlp_ratio"], qkv_bias=True, num_classes=cfg["num_classes"],
             pruning_loc=list(cfg["pruning_loc"]), token_ratio=list(cfg["token_ratio"]), distill=True,
-            topk_selection=True, small_predictor=cfg["small_predictor"], predictor_loss_type=cfg["loss_type"])
+            topk_selection=True, small_predictor=cfg["small_predictor"], predictor_loss_type=cfg["loss_type"],
+            predictor_bn=bool(cfg.get("predictor_bn")))
         teacher = dv.VisionTransformerTeacher(
             img_size=cfg["img_size"], patch_size=cfg["patch"], embed_dim=cfg["dim"], depth=cfg["depth"],
             num_heads=cfg["heads"], mlp_ratio=cfg["mlp_ratio"], qkv_bias=True, num_classes=cfg["num_classes"])
@@ -186,6 +188,10 @@ def gen_model_case(dv, losses, name):
     out["grad_names"] = np.array(names)
     out["grad_norms"] = np.array(norms, np.float64)
     out["grad_heads"] = np.stack(heads)
+
+    for k_, v in student.state_dict().items():          # BatchNorm running estimates after this one training step (predictor_bn)
+        if k_.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            out["buf_" + k_] = _np(v)
 
     # predictor-only gradient probe: logits.sum().backward() leaves predictors at None
     # ---- eval-mode forward (dynamic_vit.py:1015) ----
