@@ -40,7 +40,8 @@ def check_supported(args):
     if args.early_exit:
         bad.append("--early-exit")
     if args.random_drop:
-        bad.append("--random-drop")
+        # stored on the model and used for the job name only (dynamic_vit.py:748, mask_predictor.py:79-80): no effect on the forward
+        print("Attention: --random-drop has no effect on the forward pass at this commit of the reference (attribute only)")
     if args.mask_loss_type not in ("kl_div", "mse"):
         bad.append(f"--mask-loss-type {args.mask_loss_type} (kl_div and mse are on the path; bce is broken in the reference)")
     if args.use_dp:
