@@ -33,8 +33,6 @@ _TEACHERS = {"deit_tiny": "dynamic_vit_tiny_patch16_224_teacher", "deit_small": 
 def check_supported(args):
     """Flags whose code path is outside the accelerated hot path fail here, loudly, instead of silently training something else."""
     bad = []
-    if args.predictor_bn and args.small_predictor:
-        bad.append("--predictor-bn together with --small-predictor (only the large BatchNorm predictor is on the path)")
     if args.patch_score_threshold is not None:
         bad.append("--patch-score-threshold (broken in the reference: dynamic_vit.py:936, losses.py:216-218)")
     if args.early_exit:

@@ -159,11 +159,16 @@ class PredictorLG(nn.Module):
 
     def __init__(self, embed_dim=384, topk_selection=False, k=None, small_predictor=False, loss_type="kl_div", use_bn=False):
         super().__init__()
-        if use_bn and small_predictor:
-            raise NotImplementedError("the small BatchNorm predictor (:383-400) is not on the accelerated path; the large one (:438-476) is")
         self.small_predictor, self.k, self.topk_selection, self.loss_type, self.use_bn = small_predictor, k, topk_selection, loss_type, use_bn
         D = embed_dim
         relu = nn.ReLU()
+        if use_bn and small_predictor:      # :383-400: small BatchNorm predictor (ReLU, unlike the small LayerNorm one which uses GELU)
+            self.in_conv = nn.Sequential(BatchNormLayer(D), nn.Linear(D, D), relu)
+            self.out_conv = nn.Sequential(BatchNormLayer(D), nn.Linear(D, D // 2), relu, BatchNormLayer(D // 2),
+                                          nn.Linear(D // 2, D // 4), relu, BatchNormLayer(D // 4), nn.Linear(D // 4, 1),
+                                          nn.Flatten(start_dim=-2, end_dim=-1))
+            self.topk = PerturbedTopK(k)
+            return
         if use_bn:               # :438-476: the large predictor with BatchNormLayer in place of every LayerNorm
             self.in_conv = nn.Sequential(BatchNormLayer(D), nn.Linear(D, D * 4), relu)
             self.out_conv = nn.Sequential(
@@ -198,7 +203,7 @@ class PredictorLG(nn.Module):
         return ps
 
     def _bn_layers(self):
-        return [self.in_conv[0].bn] + [self.out_conv[i].bn for i in (0, 3, 6, 9, 12)]
+        return [self.in_conv[0].bn] + [self.out_conv[i].bn for i in ((0, 3, 6) if self.small_predictor else (0, 3, 6, 9, 12))]
 
     def forward_tokens(self, x_with_cls):
         """Scores for x[:, 1:] of a [B, n, D] tensor, read in place (no slice copy).  -> (scores, keep_probs)."""

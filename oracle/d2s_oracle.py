@@ -61,7 +61,7 @@ def student_param_shapes(cfg):
     for s in range(len(cfg["pruning_loc"])):
         p = f"score_predictor.{s}."
         if cfg["small_predictor"]:
-            out += [(p + "in_conv.0.weight", (D,)), (p + "in_conv.0.bias", (D,)),
+            out += [(p + f"in_conv.0.{bn}weight", (D,)), (p + f"in_conv.0.{bn}bias", (D,)),
                     (p + "in_conv.1.weight", (D, D)), (p + "in_conv.1.bias", (D,))]
             widths = [D, D // 2, D // 4, 1]
             idx = [0, 1, 3, 4, 6, 7]
@@ -152,9 +152,9 @@ def predictor(sd, s, x, cfg, margins=None, training=True, bn_state=None):
     nn.LayerNorm / nn.BatchNorm1d default eps 1e-5.  Returns (scores, keep_probs) each [B, n-1]."""
     p = f"score_predictor.{s}."
     small = cfg["small_predictor"]
-    act = F.gelu if small else F.relu
-    D = cfg["dim"]
     use_bn = bool(cfg.get("predictor_bn"))
+    act = F.gelu if (small and not use_bn) else F.relu      # the small BatchNorm variant keeps self.act = ReLU (:383-400)
+    D = cfg["dim"]
 
     def norm(h, key):
         if not use_bn:

@@ -30,6 +30,8 @@ MODEL_CASES = {
     # --predictor-bn: the large predictor with BatchNormLayer instead of LayerNorm (dynamic_vit.py:438-476)
     "micro_bn": dict(cfg=O.make_cfg(img_size=64, dim=128, depth=3, heads=2, num_classes=10,
                                     pruning_loc=(1,), token_ratio=(0.05,), predictor_bn=True), batch=4, seed=14),
+    "micro_small_bn": dict(cfg=O.make_cfg(img_size=64, dim=128, depth=3, heads=2, num_classes=10, pruning_loc=(1,), token_ratio=(0.05,),
+                                          small_predictor=True, predictor_bn=True), batch=4, seed=15),
     # G2: BASELINE config 1 - DeiT-Tiny, 32x32, keep 1.0, batch 4 (N = 4, gather is the identity)
     "tiny32": dict(cfg=O.make_cfg(img_size=32, dim=192, depth=12, heads=3, pruning_loc=(3,),
                                   token_ratio=(1.0,)), batch=4, seed=21),

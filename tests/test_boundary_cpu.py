@@ -117,7 +117,7 @@ def test_cli_accepts_every_reference_flag_with_the_same_default():
 def test_cli_rejects_flags_outside_the_path():
     import mask_predictor
     import utils
-    for extra in (["--predictor-bn", "--small-predictor"], ["--patch-score-threshold", "0.9"], ["--early-exit"], ["--mask-loss-type", "bce"], ["--use-dp"]):
+    for extra in (["--patch-score-threshold", "0.9"], ["--early-exit"], ["--mask-loss-type", "bce"], ["--use-dp"]):
         with pytest.raises(SystemExit, match="not on the accelerated path"):
             mask_predictor.check_supported(utils.parse_args(extra))
     a = utils.parse_args([])
