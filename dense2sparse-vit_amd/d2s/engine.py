@@ -99,8 +99,9 @@ class FusedAdamW:
         desc = np.zeros(a.n_chunks, dtype=[("lr", "<f4"), ("wd", "<f4"), ("active", "<i4"), ("pad", "<i4")])
         for i, (g, p) in enumerate(zip(self.groups, a.params_list)):
             c0, c1 = a.chunk_range(i)
-            if g is None or not p.requires_grad:
-                continue
+            if g is None or g == "early_exit" or not p.requires_grad:
+                continue      # early_exit: the head is never called (dynamic_vit.py:752-758), its gradients stay None and torch's AdamW
+                              # skips such parameters entirely - so does this one
             desc["lr"][c0:c1] = self.group_lr[g]
             desc["wd"][c0:c1] = self.group_wd[g]
             desc["active"][c0:c1] = 1

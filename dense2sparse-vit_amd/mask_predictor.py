@@ -36,7 +36,7 @@ def check_supported(args):
     if args.patch_score_threshold is not None:
         bad.append("--patch-score-threshold (broken in the reference: dynamic_vit.py:936, losses.py:216-218)")
     if args.early_exit:
-        bad.append("--early-exit")
+        print("Attention: --early-exit creates the extra head but, as in the reference, nothing calls it (dynamic_vit.py:752-758)")
     if args.random_drop:
         # stored on the model and used for the job name only (dynamic_vit.py:748, mask_predictor.py:79-80): no effect on the forward
         print("Attention: --random-drop has no effect on the forward pass at this commit of the reference (attribute only)")

@@ -298,8 +298,10 @@ class VisionTransformerDiffPruning(_ViTBase):
         if patch_score_threshold is not None:
             raise NotImplementedError("patch_score_threshold (dynamic keep ratio) is broken in the reference (dynamic_vit.py:936, "
                                       "losses.py:216-218) and not on the accelerated hot path (SURVEY 8f.3)")
-        if early_exit:
-            raise NotImplementedError("early_exit head is not on the hot path")
+        if early_exit:      # :752-758: the head is created (state-dict keys, 'early_exit' parameter group) but no forward path of the
+            # reference ever calls it, so its parameters never receive a gradient and the optimiser never moves them
+            self.early_exit_head = nn.Sequential((norm_layer or partial(nn.LayerNorm, eps=1e-6))(embed_dim),
+                                                 nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity())
         pruning_loc = list(pruning_loc or [])
         token_ratio = list(token_ratio or [])
         isz = img_size if isinstance(img_size, int) else img_size[0]

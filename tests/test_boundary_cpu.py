@@ -117,7 +117,7 @@ def test_cli_accepts_every_reference_flag_with_the_same_default():
 def test_cli_rejects_flags_outside_the_path():
     import mask_predictor
     import utils
-    for extra in (["--patch-score-threshold", "0.9"], ["--early-exit"], ["--mask-loss-type", "bce"], ["--use-dp"]):
+    for extra in (["--patch-score-threshold", "0.9"], ["--mask-loss-type", "bce"], ["--use-dp"]):
         with pytest.raises(SystemExit, match="not on the accelerated path"):
             mask_predictor.check_supported(utils.parse_args(extra))
     a = utils.parse_args([])
@@ -153,3 +153,13 @@ def test_checkpoint_ingestion_matches_reference_fixture():
         m2 = vit_models.dynamic_vit_tiny_patch16_224_teacher(checkpoint_path=path)
     assert m2.pos_embed.shape == (1, 197, 192)
     np.testing.assert_allclose(m2.pos_embed[:, :1].detach().numpy(), sd["pos_embed"][:, :1].numpy())
+
+
+def test_early_exit_head_is_a_parameter_container_like_the_reference():
+    import vit_models
+    m = vit_models.VisionTransformerDiffPruning(img_size=64, embed_dim=128, depth=2, num_heads=2, num_classes=10, pruning_loc=[1],
+                                                token_ratio=[0.5], distill=True, topk_selection=True, predictor_loss_type="kl_div",
+                                                early_exit=True)
+    keys = set(m.state_dict())
+    assert {"early_exit_head.0.weight", "early_exit_head.0.bias", "early_exit_head.1.weight", "early_exit_head.1.bias"} <= keys
+    assert m.state_dict()["early_exit_head.1.weight"].shape == (10, 128)

@@ -88,3 +88,28 @@ def test_mask_loss_mse_branch_matches_reference_fixture():
     np.testing.assert_allclose(p0.grad.cpu().numpy(), g["g0"], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(p1.grad.cpu().numpy(), g["g1"], rtol=1e-4, atol=1e-7)
     assert sorted(metrics) == [str(k) for k in g["metric_keys"]]
+
+
+def test_early_exit_head_is_never_updated():
+    """--early-exit: the extra head exists (keys, 'early_exit' group) but nothing calls it; like torch's AdamW on grad-None parameters,
+    the fused optimiser must leave it untouched while everything else trains."""
+    import vit_models
+    from d2s.engine import TrainStep
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    kw = dict(img_size=64, embed_dim=128, depth=3, num_heads=2, num_classes=10)
+    s = vit_models.VisionTransformerDiffPruning(pruning_loc=[1], token_ratio=[0.05], distill=True, topk_selection=True,
+                                                predictor_loss_type="kl_div", early_exit=True, **kw).to(dev)
+    t = vit_models.VisionTransformerTeacher(**kw).to(dev)
+    args = types.SimpleNamespace(keep_ratios=[0.05], mask_loss_type="kl_div", mixup=0.0, patch_score_threshold=None, step=0)
+    ts = TrainStep(s, t, args, lr=1e-3, weight_decay=0.05, warmup_steps=0)
+    before = {k: v.clone() for k, v in s.state_dict().items()}
+    x = torch.randn(4, 3, 64, 64, device=dev)
+    y = torch.randint(0, 10, (4,), device=dev)
+    for _ in range(2):
+        ts(x, y)
+    after = s.state_dict()
+    for k in before:
+        if k.startswith("early_exit_head."):
+            assert torch.equal(before[k], after[k]), k
+    assert not torch.equal(before["blocks.0.mlp.fc1.weight"], after["blocks.0.mlp.fc1.weight"])
