@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void gather_renorm_kernel(const float* __restr
     for (int j = tid; j < k; j += 256) out[(long)blockIdx.x * k + j] = normalize ? ib[idb[j]] / tot : ib[idb[j]];
 }
 
-enum KlMode : int { KL_LOGIT_TARGET = 0, KL_PROB_TARGET = 1, CE_LABEL = 2, MSE_TARGET = 3 };
+enum KlMode : int { KL_LOGIT_TARGET = 0, KL_PROB_TARGET = 1, CE_LABEL = 2, MSE_TARGET = 3, SOFT_CE = 4 };
 
 // one wave per row.  loss_row[r], grad[r][:] = d loss_row / d s[r][:]
 template <int NE>
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void kl_rows_kernel(const float* __restrict__ 
     for (int i = 0; i < NE; ++i) {
         const int c = lane + i * 64;
         sv[i] = c < C ? sr[c] : -INFINITY;
-        tv[i] = (tr && c < C) ? tr[c] : ((mode == KL_PROB_TARGET || mode == MSE_TARGET) ? 0.f : -INFINITY);
+        tv[i] = (tr && c < C) ? tr[c] : ((mode == KL_PROB_TARGET || mode == MSE_TARGET || mode == SOFT_CE) ? 0.f : -INFINITY);
         ms = fmaxf(ms, sv[i]);
         if (mode == KL_LOGIT_TARGET) mt = fmaxf(mt, tv[i]);
     }
@@ -125,6 +125,20 @@ __global__ __launch_bounds__(256) void kl_rows_kernel(const float* __restrict__ 
             if (c < C) {
                 const float ls = sv[i] - lse_s;
                 loss += tv[i] * (logf(tv[i]) - ls);
+                if (gr) gr[c] = expf(ls) * tsum - tv[i];
+            }
+        }
+    } else if (mode == SOFT_CE) {         // soft-target cross entropy (timm SoftTargetCrossEntropy under mixup, losses.py:170-172):
+        float tsum = 0.f;                 // -sum_c t_c log_softmax(s)_c; zero targets contribute nothing
+#pragma unroll
+        for (int i = 0; i < NE; ++i) tsum += tv[i];
+        tsum = wave_sum(tsum);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int c = lane + i * 64;
+            if (c < C) {
+                const float ls = sv[i] - lse_s;
+                loss -= tv[i] * ls;
                 if (gr) gr[c] = expf(ls) * tsum - tv[i];
             }
         }
@@ -249,13 +263,13 @@ int d2s_gather_renorm(const float* in, const long long* ids, float* out, int B, 
 }
 
 // mode 0: KL(log_softmax(s) || log_softmax(t)) per row; 1: KL with t given as probabilities; 2: cross entropy with labels;
-// 3: sum of squared differences s - t (the mse mask loss).
+// 3: sum of squared differences s - t (the mse mask loss); 4: soft-target cross entropy -sum t log_softmax(s) (mixup labels).
 // s rows through (s_*) row map, t rows through (t_*) row map plus optional t_ids[r] * t_row_stride.
 // loss_row [rows]; grad [rows, C] contiguous (may be null).  C <= 1024.
 int d2s_kl_rows(const float* s, long s_rpg, long s_gs, long s_rs, long s_off, const float* t, long t_rpg, long t_gs, long t_rs,
                 long t_off, const long long* t_ids, const long long* labels, float* loss_row, float* grad, long rows, int C,
                 int mode, hipStream_t stream) {
-    if (!s || !loss_row || rows <= 0 || C <= 0 || C > 1024 || mode < 0 || mode > 3) return D2S_ERR_ARG;
+    if (!s || !loss_row || rows <= 0 || C <= 0 || C > 1024 || mode < 0 || mode > 4) return D2S_ERR_ARG;
     if (mode == 2 ? !labels : !t) return D2S_ERR_ARG;
     RowMap sm{s_rpg, s_gs, s_rs, s_off}, tm{t_rpg > 0 ? t_rpg : 1, t_gs, t_rs, t_off};
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);

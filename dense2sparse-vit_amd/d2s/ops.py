@@ -265,7 +265,7 @@ def attn_bwd(qkv, out, dout, lse, B, n, H, scale):
     return dqkv
 
 
-KL_LOGIT_TARGET, KL_PROB_TARGET, CE_LABEL, MSE_TARGET = 0, 1, 2, 3
+KL_LOGIT_TARGET, KL_PROB_TARGET, CE_LABEL, MSE_TARGET, SOFT_CE = 0, 1, 2, 3, 4
 
 
 def teacher_target(cls_attn):

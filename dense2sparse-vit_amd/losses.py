@@ -4,7 +4,7 @@
 Differences that are deliberate and documented:
   * running statistics stay on the device (no .item() per step, losses.py:111,230-233 force a D2H sync every step);
     metrics values are 0-d tensors, `float(v)` reads them.
-  * the kl_div and mse mask losses and hard-label cross entropy (mixup off) are on the accelerated path; the reference's bce
+  * the kl_div and mse mask losses, hard-label and soft-target (mixup) cross entropy are on the accelerated path; the reference's bce
     branch is broken as written (undefined `args` / `self.mask_criterions`, losses.py:57-58).
 """
 import torch
@@ -62,8 +62,7 @@ class MaskLoss(torch.nn.Module):
 class BackboneLoss(torch.nn.Module):
     def __init__(self, args):
         super().__init__()
-        if getattr(args, "mixup", 0.) > 0.:
-            raise NotImplementedError("soft-target cross entropy (mixup) is not on the accelerated hot path")
+        self.soft_targets = getattr(args, "mixup", 0.) > 0.      # losses.py:170-174: SoftTargetCrossEntropy under mixup, else hard labels
         if getattr(args, "patch_score_threshold", None) is not None:
             raise NotImplementedError("patch_score_threshold path is broken in the reference (losses.py:216-218)")
         self.patch_score_threshold = None
@@ -76,7 +75,10 @@ class BackboneLoss(torch.nn.Module):
 
     def forward(self, logits_s, token_s, logits_t, token_t, kept_token_idx, train_labels, metrics):
         B = logits_s.shape[0]
-        cls_loss = DF.RowLossFn.apply(logits_s, ops.CE_LABEL, None, None, train_labels.contiguous(), B)          # :196
+        if self.soft_targets:      # train_labels are [B, classes] probabilities produced by the caller's mixup_fn (train.py:29-30)
+            cls_loss = DF.RowLossFn.apply(logits_s, ops.SOFT_CE, train_labels.float().contiguous(), None, None, B)
+        else:
+            cls_loss = DF.RowLossFn.apply(logits_s, ops.CE_LABEL, None, None, train_labels.contiguous(), B)      # :196
         cls_kl_loss = DF.RowLossFn.apply(logits_s, ops.KL_LOGIT_TARGET, logits_t.detach(), None, None, B)       # :198-203
         rows = token_s.shape[0] * token_s.shape[1]
         # teacher tokens gathered with the LAST stage's stage-relative ids, exactly like losses.py:212

@@ -11,8 +11,8 @@ from losses import MaskLoss, BackboneLoss
 
 def train_one_epoch(args, model, teacher_model, train_data_loader, optimizer, mixup_fn=None):
     from d2s.engine import TrainStep
-    if mixup_fn is not None:
-        raise NotImplementedError("mixup is host-side RNG + soft-target CE; not on the accelerated path")
+    if mixup_fn is not None and not getattr(args, "mixup", 0.) > 0.:
+        raise ValueError("a mixup_fn needs args.mixup > 0 so that BackboneLoss uses the soft-target cross entropy (losses.py:170-172)")
     running_loss = 0.0
     metrics = {}
     model.train()
@@ -28,6 +28,8 @@ def train_one_epoch(args, model, teacher_model, train_data_loader, optimizer, mi
     for train_step, train_data in enumerate(train_data_loader):
         train_inputs = train_data[0].to(args.device, non_blocking=True)
         train_labels = train_data[1].to(args.device, non_blocking=True)
+        if mixup_fn is not None:
+            train_inputs, train_labels = mixup_fn(train_inputs, train_labels)                        # :29-30 (the caller's transform)
         if fast:
             info = step(train_inputs, train_labels)
             mask_loss, train_loss = info["mask_loss"], info["loss"]

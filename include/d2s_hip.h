@@ -134,7 +134,8 @@ int d2s_teacher_target(const float* cls_attn, float* target, int B, int L, int H
 /* losses.py:84-90: out[b,j] = in[b,ids[b,j]] (/ row sum when normalize) */
 int d2s_gather_renorm(const float* in, const long long* ids, float* out, int B, int T, int k, int normalize, d2s_stream_t stream);
 /* per-row loss + d/ds: mode 0 KL(logsm(s)||logsm(t)) (losses.py:198-203,220-225), 1 KL with t as probabilities (:94-95),
- * 2 cross entropy with labels (:196), 3 sum of squared differences s - t (the mse mask loss, :61-73).  t rows: row map plus optional t_ids[r] * t_row_stride (teacher tokens gathered
+ * 2 cross entropy with labels (:196), 3 sum of squared differences s - t (the mse mask loss, :61-73), 4 soft-target cross entropy
+ * -sum t log_softmax(s) (mixup labels, :170-172).  t rows: row map plus optional t_ids[r] * t_row_stride (teacher tokens gathered
  * by the kept ids, losses.py:212). */
 int d2s_kl_rows(const float* s, long s_rpg, long s_gs, long s_rs, long s_off, const float* t, long t_rpg, long t_gs, long t_rs,
                 long t_off, const long long* t_ids, const long long* labels, float* loss_row, float* grad, long rows, int C,

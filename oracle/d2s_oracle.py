@@ -335,7 +335,10 @@ def backbone_loss(logits_s, token_s, logits_t, token_t, kept, labels):
     """BackboneLoss.forward, losses.py:185-227 (mixup off -> CrossEntropyLoss, :174).  The teacher tokens
     are gathered with the LAST stage's (stage-relative) ids exactly as the reference does (:212).
     Returns (total, cls_loss, cls_kl, token_kl)."""
-    cls_loss = F.cross_entropy(logits_s, labels)
+    if labels.dtype.is_floating_point:    # mixup: timm's SoftTargetCrossEntropy (losses.py:170-172) = mean_b sum_c -t log_softmax(x)
+        cls_loss = torch.sum(-labels * F.log_softmax(logits_s, dim=-1), dim=-1).mean()
+    else:
+        cls_loss = F.cross_entropy(logits_s, labels)
     cls_kl = F.kl_div(F.log_softmax(logits_s, dim=-1), F.log_softmax(logits_t, dim=-1),
                       reduction="batchmean", log_target=True)
     C = token_t.shape[-1]

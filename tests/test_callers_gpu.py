@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from tests import cases
+from oracle import d2s_oracle as O
 from tests.test_model_gpu import build_models, make_args
 
 pytestmark = pytest.mark.gpu
@@ -113,3 +114,34 @@ def test_early_exit_head_is_never_updated():
         if k.startswith("early_exit_head."):
             assert torch.equal(before[k], after[k]), k
     assert not torch.equal(before["blocks.0.mlp.fc1.weight"], after["blocks.0.mlp.fc1.weight"])
+
+
+def test_soft_target_cross_entropy_under_mixup():
+    """BackboneLoss with args.mixup > 0 uses the soft-target cross entropy (losses.py:170-172; timm's SoftTargetCrossEntropy =
+    mean_b sum_c -t log_softmax(x)) on [B, classes] label distributions from the caller's mixup_fn.  Parity: the formula itself (timm is
+    not in this image, so the reference side of this one term is restated, not imported); loss and gradient vs torch on the CPU."""
+    from losses import BackboneLoss
+    dev = torch.device("cuda:0")
+    B, C, k, D = 6, 10, 5, 32
+    g = torch.Generator().manual_seed(3)
+    logits_s = torch.randn(B, C, generator=g)
+    logits_t = torch.randn(B, C, generator=g)
+    tok_s = torch.randn(B, k, D, generator=g)
+    tok_t = torch.randn(B, 12, D, generator=g)
+    kept = torch.stack([torch.randperm(12, generator=g)[:k].sort().values for _ in range(B)])
+    lam = 0.3
+    y1, y2 = torch.randint(0, C, (B,), generator=g), torch.randint(0, C, (B,), generator=g)
+    soft = lam * torch.nn.functional.one_hot(y1, C).float() + (1 - lam) * torch.nn.functional.one_hot(y2, C).float()
+    soft = soft * 0.9 + 0.1 / C                                   # label smoothing as the mixup transform applies it
+    ls_ref = logits_s.clone().requires_grad_(True)
+    ts_ref = tok_s.clone().requires_grad_(True)
+    ref, _, _, _ = O.backbone_loss(ls_ref, ts_ref, logits_t, tok_t, [kept], soft)
+    ref.backward()
+    args = types.SimpleNamespace(mixup=0.8, patch_score_threshold=None)
+    ls = logits_s.to(dev).requires_grad_(True)
+    tsd = tok_s.to(dev).requires_grad_(True)
+    loss = BackboneLoss(args)(ls, tsd, logits_t.to(dev), tok_t.to(dev), [kept.to(dev)], soft.to(dev), {})
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(ref.detach()), rtol=2e-5)
+    np.testing.assert_allclose(ls.grad.cpu().numpy(), ls_ref.grad.numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(tsd.grad.cpu().numpy(), ts_ref.grad.numpy(), rtol=1e-4, atol=1e-7)
