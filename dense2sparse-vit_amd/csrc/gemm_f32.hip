@@ -317,6 +317,40 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *cp = accumulate ? (*cp + s) : s;
 }
 
+// 16-byte form of the same combine (N, ldc multiples of 4, 16-byte aligned bases): one thread per 4 consecutive columns, all slab loads
+// of a thread independent and in flight together.  The bias-gradient slabs are folded by the tail threads as above.
+__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __restrict__ ws, float* __restrict__ C, long ldc, int M, int N,
+                                                                int slabs, long slab_stride, int accumulate,
+                                                                const float* __restrict__ colsum_ws, float* __restrict__ colsum_out) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int nq = N >> 2;
+    const long total = (long)M * nq;
+    if (idx >= total) {
+        const long m = idx - total;
+        if (colsum_out && m < M) {
+            float s = 0.f;
+            for (int z = 0; z < slabs; ++z) s += colsum_ws[(long)z * M + m];
+            colsum_out[m] = accumulate ? colsum_out[m] + s : s;
+        }
+        return;
+    }
+    const int m = (int)(idx / nq), n = (int)(idx % nq) * 4;
+    const float* src = ws + (long)m * N + n;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < slabs; ++z) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)z * slab_stride);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += v[j];
+    }
+    f32x4* cp = reinterpret_cast<f32x4*>(C + (long)m * ldc + n);
+    if (accumulate) {
+        const f32x4 o = *cp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += o[j];
+    }
+    *cp = s;
+}
+
 // Split-K combine for the forward / dgrad layouts: sums the slabs in slab order and applies the epilogue the single-pass kernel
 // would have applied in its store (bias, ReLU / GELU (+ pre-activation copy), residual, activation-gradient masks, positional row add
 // with the CLS row remap, accumulate).  `p` carries the REAL output (C, ldc) and epilogue operands.
@@ -603,10 +637,16 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
         hipLaunchKernelGGL(splitk_reduce_epi_kernel, dim3((unsigned)((total + 255) / 256)), block, 0, stream, real,
                            static_cast<const float*>(workspace), slices, (long)M * N);
     } else if (slices > 1) {
-        const long total = (long)M * N + (colsum_out ? M : 0);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), block, 0, stream,
-                           static_cast<const float*>(workspace), realC, ldc, M, N, slices, (long)M * N, accumulate,
-                           p.colsum, colsum_out);
+        if ((N % 4 == 0) && (ldc % 4 == 0) && aligned16(realC) && aligned16(workspace) && (((long)M * N) % 4 == 0)) {
+            const long total = (long)M * (N / 4) + (colsum_out ? M : 0);
+            hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3((unsigned)((total + 255) / 256)), block, 0, stream,
+                               static_cast<const float*>(workspace), realC, ldc, M, N, slices, (long)M * N, accumulate, p.colsum, colsum_out);
+        } else {
+            const long total = (long)M * N + (colsum_out ? M : 0);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), block, 0, stream,
+                               static_cast<const float*>(workspace), realC, ldc, M, N, slices, (long)M * N, accumulate,
+                               p.colsum, colsum_out);
+        }
     }
     return d2s_check_launch();
 }
