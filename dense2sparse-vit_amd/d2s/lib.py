@@ -48,6 +48,7 @@ _SIGS = {
     "d2s_performer_attn_fwd": (I, [P, P, P, P, P, P, P, P, I, I, F, P, Z]),
     "d2s_performer_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, F, P, Z]),
     "d2s_attn_fwd_f32": (I, [P, P, P, P, I, I, I, F]),
+    "d2s_attn_fwd_bf16": (I, [P, P, P, P, I, I, I, F]),
     "d2s_attn_bwd_f32": (I, [P, P, P, P, P, P, I, I, I, F]),
     "d2s_teacher_target": (I, [P, P, I, I, I, I]),
     "d2s_gather_renorm": (I, [P, P, P, I, I, I, I]),

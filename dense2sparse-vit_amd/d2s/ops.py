@@ -2,6 +2,8 @@
 
 Conventions: fp32 contiguous device tensors unless a row map says otherwise; 2-D views [rows, features].
 """
+import os
+
 import torch
 
 from . import lib
@@ -11,6 +13,7 @@ EPI_MUL_GELU_GRAD, EPI_MUL_RELU_MASK, EPI_BIAS_ROWADD, EPI_ACCUM = 5, 6, 7, 8
 NT, NN, TN = 0, 1, 2
 
 _ws = {}
+_BF16_ATTENTION = os.environ.get("D2S_BF16_ATTENTION", "1") != "0"
 
 
 def workspace(nbytes, device):
@@ -253,7 +256,9 @@ def attn_fwd(qkv, B, n, H, scale, want_cls=True):
     out = torch.empty((B * n, H * 64), dtype=torch.float32, device=qkv.device)
     lse = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device)
     cls_row = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device) if want_cls else None
-    lib.call("d2s_attn_fwd_f32", lib.ptr(qkv), lib.ptr(out), lib.ptr(lse), lib.ptr(cls_row), B, n, H, float(scale))
+    # bf16 arithmetic mode: the two matrix products of the forward run on the bf16 matrix cores too (same outputs, fp32 backward)
+    entry = "d2s_attn_fwd_bf16" if (get_gemm_mode() == GEMM_BF16 and _BF16_ATTENTION) else "d2s_attn_fwd_f32"
+    lib.call(entry, lib.ptr(qkv), lib.ptr(out), lib.ptr(lse), lib.ptr(cls_row), B, n, H, float(scale))
     return out, lse, cls_row
 
 

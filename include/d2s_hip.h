@@ -75,6 +75,10 @@ int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, lo
  * qkv: raw output of the qkv Linear, [B, n, 3, H, 64]; out/dout: [B, n, H*64]; lse, cls_row, delta_ws: [B, H, n]. */
 int d2s_attn_fwd_f32(const float* qkv, float* out, float* lse, float* cls_row, int B, int n, int H, float scale,
                      d2s_stream_t stream);
+/* Same contract on the bf16 matrix cores (Q, K, V rounded to bf16; scores, softmax, accumulation fp32): the forward of the bf16
+ * arithmetic mode.  The fp32 backward below works from its outputs unchanged. */
+int d2s_attn_fwd_bf16(const float* qkv, float* out, float* lse, float* cls_row, int B, int n, int H, float scale,
+                      d2s_stream_t stream);
 int d2s_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws,
                      int B, int n, int H, float scale, d2s_stream_t stream);
 

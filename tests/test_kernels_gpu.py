@@ -450,3 +450,27 @@ def test_batchnorm_fwd_bwd(ops, R, C, training):
     np.testing.assert_allclose(db.cpu().numpy(), br.grad.float().numpy(), rtol=2e-4, atol=2e-4)
     dxm = ops.batchnorm_bwd(x.to(d), dy.to(d), w.to(d), mean, rstd, None, None, training, relu_mask=True)
     np.testing.assert_allclose(dxm.cpu().numpy(), (xr.grad.float() * (x > 0)).numpy(), rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,n,H", [(2, 197, 6), (3, 99, 3), (1, 577, 2), (2, 32, 1), (1, 33, 1), (1, 1, 1), (2, 41, 2), (1, 130, 1)])
+def test_attention_fwd_bf16_mode(ops, B, n, H):
+    """d2s_attn_fwd_bf16 (bf16 arithmetic mode): output, log-sum-exp and CLS row against the fp32 reference within bf16 operand rounding
+    (2^-9 relative on q, k, v), and the fp32 backward run from ITS outputs stays close to autograd's gradients."""
+    qkv = _rand("aqb", (B * n, 3 * H * 64), 1.0, seed=n)
+    qr = qkv.clone().requires_grad_(True)
+    o_ref, cls_ref, lse_ref = _attn_ref(qr, B, n, H)
+    do = _rand("adob", (B, n, H * 64), 1.0, seed=n + 1)
+    o_ref.backward(do)
+    qd = qkv.to(_dev())
+    ops.set_gemm_mode(ops.GEMM_BF16)
+    try:
+        out, lse, cls_row = ops.attn_fwd(qd, B, n, H, 0.125)
+        dqkv = ops.attn_bwd(qd, out, do.reshape(B * n, -1).to(_dev()), lse, B, n, H, 0.125)
+    finally:
+        ops.set_gemm_mode(ops.GEMM_EXACT)
+    np.testing.assert_allclose(out.cpu().numpy().reshape(B, n, -1), o_ref.detach().numpy(), rtol=3e-2, atol=3e-2)
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_ref.detach().numpy(), rtol=2e-2, atol=3e-2)
+    np.testing.assert_allclose(cls_row.cpu().numpy(), cls_ref.detach().numpy(), rtol=0.1, atol=2e-3)
+    np.testing.assert_allclose(cls_row.cpu().numpy().sum(-1), np.ones((B, H), np.float32), rtol=1e-4)
+    err = (dqkv.cpu() - qr.grad).norm() / qr.grad.norm()
+    assert float(err) < 3e-2, float(err)

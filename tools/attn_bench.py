@@ -21,3 +21,29 @@ for n in (197, 99):
         e.record(); torch.cuda.synchronize()
         us = s.elapsed_time(e) * 1000 / 30
         print(f"n {n:4d} {name} {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s (algorithmic, unpadded)")
+
+print("bf16 arithmetic mode (forward on the bf16 matrix cores):")
+ops.set_gemm_mode(ops.GEMM_BF16)
+for n in (197, 99, 577):
+    Bn = B if n != 577 else 64
+    Hn = H if n != 577 else 12
+    qkv = torch.randn(Bn * n, 3 * Hn * 64, device=dev)
+    for _ in range(3): ops.attn_fwd(qkv, Bn, n, Hn, 0.125)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(30): ops.attn_fwd(qkv, Bn, n, Hn, 0.125)
+    e.record(); torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1000 / 30
+    print(f"n {n:4d} B {Bn} H {Hn} fwd bf16 {us:8.1f} us  {4.0 * n * n * 64 * Bn * Hn / us / 1e6:7.1f} TF/s (algorithmic, unpadded)")
+ops.set_gemm_mode(ops.GEMM_EXACT)
+for n in (577,):
+    qkv = torch.randn(64 * n, 3 * 12 * 64, device=dev)
+    for _ in range(3): ops.attn_fwd(qkv, 64, n, 12, 0.125)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(10): ops.attn_fwd(qkv, 64, n, 12, 0.125)
+    e.record(); torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1000 / 10
+    print(f"n {n:4d} B 64 H 12 fwd fp32 {us:8.1f} us  {4.0 * n * n * 64 * 64 * 12 / us / 1e6:7.1f} TF/s")
