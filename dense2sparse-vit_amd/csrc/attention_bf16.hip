@@ -1,6 +1,6 @@
-// Attention forward on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), head dim 64: the forward of the bf16 arithmetic mode
-// (d2s_set_gemm_mode(2); BASELINE config 5's regime).  Same contract as d2s_attn_fwd_f32 - fp32 qkv in, fp32 out / log-sum-exp /
-// CLS softmax row out - so the fp32 backward kernels (recompute from the saved log-sum-exp) keep working unchanged.  Q, K, V are
+// Attention on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), head dim 64: forward and backward of the bf16 arithmetic mode
+// (d2s_set_gemm_mode(2); BASELINE config 5's regime).  Same contracts as d2s_attn_fwd_f32 / d2s_attn_bwd_f32 - fp32 qkv in, fp32 out /
+// log-sum-exp / CLS softmax row / dqkv out - so either backward can run from either forward's outputs.  Q, K, V are
 // rounded to bf16 on their way into registers / LDS, the scores, the softmax and both accumulations are fp32.
 //
 // Orientation (no cross-lane traffic for P, no shuffles for the rescale): S^T = K Q^T as in the fp32 kernel - a lane owns ONE query
@@ -166,6 +166,199 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const float* __re
     }
 }
 
+// staging helpers shared by the backward kernels: thread -> (row = tid / 8 of the 32-row tile, 8 consecutive d)
+__device__ __forceinline__ void stage_rows(const float* __restrict__ base, long ld, int row0, int n, int tid, f32x4 (&r)[2]) {
+    const long row = min(row0 + (tid >> 3), n - 1);          // clamped: consumers mask by index / by lse = +inf
+    const float* p = base + row * ld + (tid & 7) * 8;
+    r[0] = *reinterpret_cast<const f32x4*>(p);
+    r[1] = *reinterpret_cast<const f32x4*>(p + 4);
+}
+__device__ __forceinline__ void put_rows(__bf16* __restrict__ S, int tid, const f32x4 (&r)[2], float scale) {      // [row][d], pitch KP
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = (__bf16)(r[0][j] * scale); v[4 + j] = (__bf16)(r[1][j] * scale); }
+    *reinterpret_cast<bf16x8*>(&S[(tid >> 3) * KP + (tid & 7) * 8]) = v;
+}
+__device__ __forceinline__ void put_rows_t(__bf16* __restrict__ St, int tid, const f32x4 (&r)[2]) {                // [d][pos(row)], pitch VP
+    const int pos = key_pos(tid >> 3), d8 = (tid & 7) * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        St[(d8 + j) * VP + pos] = (__bf16)r[0][j];
+        St[(d8 + 4 + j) * VP + pos] = (__bf16)r[1][j];
+    }
+}
+__device__ __forceinline__ void row_frags(const float* __restrict__ base, long ld, int row, int n, int half, float scale, bf16x8 (&f)[4]) {
+    const float* p = base + (long)min(row, n - 1) * ld + 8 * half;       // this lane's own row, d = 16 kk + 8 half + j
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p + 16 * kk), c = *reinterpret_cast<const f32x4*>(p + 16 * kk + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[kk][j] = (__bf16)(a[j] * scale); f[kk][4 + j] = (__bf16)(c[j] * scale); }
+    }
+}
+__device__ __forceinline__ void pack2(const f32x16& s, bf16x8 (&pf)[2]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[kk][j] = (__bf16)s[8 * kk + j];
+}
+// acc^T[dt] += T^T-tile (LDS [d][pos]) x packed registers: the O^T = V^T P^T step of the forward, reused by every backward product
+__device__ __forceinline__ void mma_t(const __bf16* __restrict__ St, const bf16x8 (&pf)[2], int l31, int half, f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 tf = *reinterpret_cast<const bf16x8*>(&St[(32 * dt + l31) * VP + 16 * kk + 8 * half]);
+            acc[dt] = mfma_bf16(tf, pf[kk], acc[dt]);
+        }
+}
+// acc[rows of the LDS tile][this lane's own row] = tile (LDS [row][d]) x this lane's fragments
+__device__ __forceinline__ f32x16 mma_rows(const __bf16* __restrict__ S, const bf16x8 (&f)[4], int l31, int half) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const bf16x8 tf = *reinterpret_cast<const bf16x8*>(&S[l31 * KP + 16 * kk + 8 * half]);
+        acc = mfma_bf16(tf, f[kk], acc);
+    }
+    return acc;
+}
+__device__ __forceinline__ void store_t(const f32x16 (&acc)[2], float* __restrict__ p, int half, float mul) {     // acc^T -> one row of 64 d
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[dt][4 * g + j] * mul;
+            *reinterpret_cast<f32x4*>(p + 32 * dt + 8 * g + 4 * half) = v;
+        }
+}
+
+// ---- backward, dQ: a lane owns one query; loop over key tiles (S^T, dP^T, dS^T lane-local, dQ^T = K^T dS^T) ------------------------
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                  float* __restrict__ dqkv, int n, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[32 * KP];
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[32 * KP];
+    __shared__ __attribute__((aligned(16))) __bf16 Kt[DH * VP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const long ld = 3L * H * DH, ldo = (long)H * DH;
+    const float* qb = qkv + (long)b * n * ld + h * DH;
+    const float* kb = qb + (long)H * DH;
+    const float* vb = kb + (long)H * DH;
+    const float* dob = dout + (long)b * n * ldo + h * DH;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bool active = q0 < n, qok = q0 + l31 < n;
+    bf16x8 qf[4], dof[4];
+    row_frags(qb, ld, q0 + l31, n, half, scale, qf);
+    row_frags(dob, ldo, q0 + l31, n, half, 1.0f, dof);
+    const float lse_i = qok ? lse[((long)b * H + h) * n + q0 + l31] : INFINITY;
+    const float dl_i = qok ? delta[((long)b * H + h) * n + q0 + l31] : 0.f;
+    f32x16 dq[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+    const int ntiles = (n + 31) / 32;
+    f32x4 kr[2], vr[2];
+    stage_rows(kb, ld, 0, n, tid, kr);
+    stage_rows(vb, ld, 0, n, tid, vr);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        put_rows(Ks, tid, kr, 1.0f);
+        put_rows(Vs, tid, vr, 1.0f);
+        put_rows_t(Kt, tid, kr);
+        __syncthreads();
+        const int tn = min(t + 1, ntiles - 1) * 32;
+        stage_rows(kb, ld, tn, n, tid, kr);
+        stage_rows(vb, ld, tn, n, tid, vr);
+        if (!active) continue;
+        f32x16 s = mma_rows(Ks, qf, l31, half);        // scaled scores^T [key][query]
+        const f32x16 dp = mma_rows(Vs, dof, l31, half);  // dP^T[key][query] = sum_d V[key][d] dO[query][d]
+        const int kv0 = t * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = (kv0 + mfma32_row(r, half) < n) ? __expf(s[r] - lse_i) : 0.f;
+            s[r] = p * (dp[r] - dl_i);                   // dS^T
+        }
+        bf16x8 pf[2];
+        pack2(s, pf);
+        mma_t(Kt, pf, l31, half, dq);                    // dQ^T[d][query] += sum_key K[key][d] dS^T[key][query]
+    }
+    if (active && qok) store_t(dq, dqkv + ((long)b * n + q0 + l31) * ld + h * DH, half, scale);
+}
+
+// ---- backward, dK / dV: a lane owns one key; loop over query tiles ------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                   float* __restrict__ dqkv, int n, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) __bf16 Qs[32 * KP];
+    __shared__ __attribute__((aligned(16))) __bf16 Ds[32 * KP];
+    __shared__ __attribute__((aligned(16))) __bf16 Qt[DH * VP];
+    __shared__ __attribute__((aligned(16))) __bf16 Dt[DH * VP];
+    __shared__ float lse_s[32], dl_s[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const long ld = 3L * H * DH, ldo = (long)H * DH;
+    const float* qb = qkv + (long)b * n * ld + h * DH;
+    const float* kb = qb + (long)H * DH;
+    const float* vb = kb + (long)H * DH;
+    const float* dob = dout + (long)b * n * ldo + h * DH;
+    const float* lse_b = lse + ((long)b * H + h) * n;
+    const float* dl_b = delta + ((long)b * H + h) * n;
+    const int k0 = blockIdx.x * 128 + wave * 32;
+    const bool active = k0 < n, kok = k0 + l31 < n;
+    bf16x8 kf[4], vf[4];
+    row_frags(kb, ld, k0 + l31, n, half, scale, kf);     // scaled copy: only the scores use it
+    row_frags(vb, ld, k0 + l31, n, half, 1.0f, vf);
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+    const int ntiles = (n + 31) / 32;
+    f32x4 qr[2], dr[2];
+    float lr, dlr;
+    auto fetch = [&](int row0) {
+        stage_rows(qb, ld, row0, n, tid, qr);
+        stage_rows(dob, ldo, row0, n, tid, dr);
+        const int qi = row0 + (tid & 31), qc = min(qi, n - 1);
+        const float l0 = lse_b[qc], d0 = dl_b[qc];
+        lr = qi < n ? l0 : INFINITY;                     // queries past the sequence: p = exp(s - inf) = 0
+        dlr = qi < n ? d0 : 0.f;
+    };
+    fetch(0);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        put_rows(Qs, tid, qr, 1.0f);
+        put_rows(Ds, tid, dr, 1.0f);
+        put_rows_t(Qt, tid, qr);
+        put_rows_t(Dt, tid, dr);
+        if (tid < 32) { lse_s[tid] = lr; dl_s[tid] = dlr; }
+        __syncthreads();
+        fetch(min(t + 1, ntiles - 1) * 32);
+        if (!active) continue;
+        f32x16 s = mma_rows(Qs, kf, l31, half);          // S[query = row(r, half)][key = l31], scaled
+        f32x16 dp = mma_rows(Ds, vf, l31, half);         // dP[query][key] = sum_d dO[query][d] V[key][d]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = mfma32_row(r, half);
+            const float p = __expf(s[r] - lse_s[qi]);
+            s[r] = p;
+            dp[r] = p * (dp[r] - dl_s[qi]);
+        }
+        bf16x8 pf[2], dsf[2];
+        pack2(s, pf);
+        pack2(dp, dsf);
+        mma_t(Dt, pf, l31, half, dv);                    // dV^T[d][key] += sum_query dO[query][d] P[query][key]
+        mma_t(Qt, dsf, l31, half, dk);                   // dK^T[d][key] += sum_query Q[query][d] dS[query][key]
+    }
+    if (active && kok) {
+        float* row = dqkv + ((long)b * n + k0 + l31) * ld + h * DH;
+        store_t(dk, row + (long)H * DH, half, scale);
+        store_t(dv, row + 2L * H * DH, half, 1.0f);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -177,6 +370,20 @@ int d2s_attn_fwd_bf16(const float* qkv, float* out, float* lse, float* cls_row, 
     dim3 grid((n + 127) / 128, B * H), block(256);
     hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, block, cls_row ? (size_t)n * sizeof(float) : 0, stream, qkv, out, lse, cls_row, n, H,
                        scale);
+    return d2s_check_launch();
+}
+
+int d2s_attn_delta(const float* out, const float* dout, float* delta, int B, int n, int H, hipStream_t stream);
+
+// Backward of the same mode (same contract as d2s_attn_bwd_f32): dqkv [B,n,3,H,64] fully written; delta_ws: [B,H,n] floats of scratch.
+int d2s_attn_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws, int B, int n,
+                      int H, float scale, hipStream_t stream) {
+    if (!qkv || !out || !dout || !lse || !dqkv || !delta_ws || B <= 0 || n <= 0 || H <= 0) return D2S_ERR_ARG;
+    const int rc = d2s_attn_delta(out, dout, delta_ws, B, n, H, stream);
+    if (rc != D2S_OK) return rc;
+    dim3 grid((n + 127) / 128, B * H), block(256);
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, n, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, n, H, scale);
     return d2s_check_launch();
 }
 

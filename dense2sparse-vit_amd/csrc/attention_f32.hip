@@ -365,6 +365,14 @@ int d2s_attn_fwd_f32(const float* qkv, float* out, float* lse, float* cls_row, i
     return d2s_check_launch();
 }
 
+// delta[b,h,i] = sum_d dout[b,i,h,d] * out[b,i,h,d]: the row term of the softmax backward, shared by the fp32 and bf16 backward kernels
+int d2s_attn_delta(const float* out, const float* dout, float* delta, int B, int n, int H, hipStream_t stream) {
+    if (!out || !dout || !delta || B <= 0 || n <= 0 || H <= 0) return D2S_ERR_ARG;
+    const long rows = (long)B * n;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, out, dout, delta, rows, n, H);
+    return d2s_check_launch();
+}
+
 // dqkv [B,n,3,H,64] is fully written.  delta_ws: [B,H,n] floats of scratch.
 int d2s_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws, int B,
                      int n, int H, float scale, hipStream_t stream) {

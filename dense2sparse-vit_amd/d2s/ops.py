@@ -265,8 +265,8 @@ def attn_fwd(qkv, B, n, H, scale, want_cls=True):
 def attn_bwd(qkv, out, dout, lse, B, n, H, scale):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device)
-    lib.call("d2s_attn_bwd_f32", lib.ptr(qkv), lib.ptr(out), lib.ptr(dout), lib.ptr(lse), lib.ptr(dqkv), lib.ptr(delta), B, n, H,
-             float(scale))
+    entry = "d2s_attn_bwd_bf16" if (get_gemm_mode() == GEMM_BF16 and _BF16_ATTENTION) else "d2s_attn_bwd_f32"
+    lib.call(entry, lib.ptr(qkv), lib.ptr(out), lib.ptr(dout), lib.ptr(lse), lib.ptr(dqkv), lib.ptr(delta), B, n, H, float(scale))
     return dqkv
 
 

@@ -81,6 +81,11 @@ int d2s_attn_fwd_bf16(const float* qkv, float* out, float* lse, float* cls_row, 
                       d2s_stream_t stream);
 int d2s_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws,
                      int B, int n, int H, float scale, d2s_stream_t stream);
+/* delta[b,h,i] = sum_d dout * out (row term of the softmax backward); the two backward entries call it themselves */
+int d2s_attn_delta(const float* out, const float* dout, float* delta, int B, int n, int H, d2s_stream_t stream);
+/* backward on the bf16 matrix cores (bf16 arithmetic mode), same contract as d2s_attn_bwd_f32 */
+int d2s_attn_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws,
+                     int B, int n, int H, float scale, d2s_stream_t stream);
 
 /* Attention.softmax_with_policy (vit_models/dynamic_vit.py:195-214) on materialised scores [B,H,N,N], policy [B,N];
  * the backward includes the path through the row maximum (the reference does not detach it). */

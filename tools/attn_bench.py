@@ -36,6 +36,15 @@ for n in (197, 99, 577):
     e.record(); torch.cuda.synchronize()
     us = s.elapsed_time(e) * 1000 / 30
     print(f"n {n:4d} B {Bn} H {Hn} fwd bf16 {us:8.1f} us  {4.0 * n * n * 64 * Bn * Hn / us / 1e6:7.1f} TF/s (algorithmic, unpadded)")
+    out, lse, _ = ops.attn_fwd(qkv, Bn, n, Hn, 0.125)
+    dout = torch.randn(Bn * n, Hn * 64, device=dev)
+    for _ in range(3): ops.attn_bwd(qkv, out, dout, lse, Bn, n, Hn, 0.125)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(20): ops.attn_bwd(qkv, out, dout, lse, Bn, n, Hn, 0.125)
+    e.record(); torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1000 / 20
+    print(f"n {n:4d} B {Bn} H {Hn} bwd bf16 {us:8.1f} us  {10.0 * n * n * 64 * Bn * Hn / us / 1e6:7.1f} TF/s")
 ops.set_gemm_mode(ops.GEMM_EXACT)
 for n in (577,):
     qkv = torch.randn(64 * n, 3 * 12 * 64, device=dev)
