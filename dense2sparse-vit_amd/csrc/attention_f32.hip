@@ -82,6 +82,24 @@ __device__ __forceinline__ void mma_reg_lds(const f32x16& p, const float* __rest
     }
 }
 
+// Transposed form of the same product: o[dt][r] = O^T[d = 32 dt + row(r, half)][query = l31].  The LDS tile row supplies the A operand
+// and the accumulator-layout registers the B operand, so the output COLUMN is the lane's own query: the running-maximum rescale and the
+// final 1 / l of the forward are lane-local (no cross-lane broadcast of alpha).
+__device__ __forceinline__ void mma_lds_reg_t(const f32x16& p, const float* __restrict__ S, int l31, int half, f32x16 (&o)[2],
+                                              int groups = 4) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g < groups) {
+#pragma unroll
+            for (int r = 4 * g; r < 4 * g + 4; ++r) {
+                const float* row = &S[mfma32_row(r, half) * PITCH];
+                o[0] = mfma32(row[l31], p[r], o[0]);
+                o[1] = mfma32(row[32 + l31], p[r], o[1]);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------
@@ -153,27 +171,27 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const float* __restric
         rs += __shfl_xor(rs, 32, 64);
         l_run = l_run * alpha + rs;
         m_run = m_new;
-        // rescale O: row (query) of O register r in this lane is row(r,half); its alpha lives in lane row(r,half)
+        // O is kept transposed (O^T[d][query]): its column is this lane's own query, so the rescale is lane-local
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float a = __shfl(alpha, mfma32_row(r, half), 64);
-            o[0][r] *= a;
-            o[1][r] *= a;
+            o[0][r] *= alpha;
+            o[1][r] *= alpha;
         }
-        mma_reg_lds(s, Vs, l31, half, o, min(4, (n - kv0 + 7) >> 3));
+        mma_lds_reg_t(s, Vs, l31, half, o, min(4, (n - kv0 + 7) >> 3));
     }
     if (!active) return;
     const float inv_l = 1.0f / l_run;
-    float* ob = out + (long)b * n * H * DH + h * DH;
+    if (q0 + l31 < n) {      // registers 4g .. 4g+3 of o[dt] hold d = 32 dt + 8 g + 4 half + 0..3 of this lane's query
+        float* p = out + ((long)b * n + q0 + l31) * H * DH + h * DH;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int qi = mfma32_row(r, half);
-        const float il = __shfl(inv_l, qi, 64);
-        if (q0 + qi < n) {
-            float* p = ob + (long)(q0 + qi) * H * DH;
-            p[l31] = o[0][r] * il;
-            p[32 + l31] = o[1][r] * il;
-        }
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = o[dt][4 * g + j] * inv_l;
+                *reinterpret_cast<f32x4*>(p + 32 * dt + 8 * g + 4 * half) = v;
+            }
     }
     if (half == 0 && q0 + l31 < n) lse[((long)b * H + h) * n + q0 + l31] = m_run + logf(l_run);
     if (want_cls) {
