@@ -163,3 +163,57 @@ def test_early_exit_head_is_a_parameter_container_like_the_reference():
     keys = set(m.state_dict())
     assert {"early_exit_head.0.weight", "early_exit_head.0.bias", "early_exit_head.1.weight", "early_exit_head.1.bias"} <= keys
     assert m.state_dict()["early_exit_head.1.weight"].shape == (10, 128)
+
+
+def test_param_groups_and_lr_schedule_match_reference_fixture():
+    """SURVEY 8a row 17, now pinned: tests/golden/param_groups.json was produced by the reference's own get_param_groups /
+    adjust_learning_rate (their two function definitions taken from utils.py by ast and run against the reference's student class,
+    tools/gen_golden.py::gen_param_groups).  Checked here: the host mirrors in utils.py, and the fused optimiser's grouping and
+    schedule in d2s.engine - group membership by name, group learning rates, the frozen set and the top-k sigma for every epoch."""
+    import json
+    import types
+    import utils
+    import vit_models
+    from d2s import engine
+    fx = json.load(open(os.path.join(REPO, "tests", "golden", "param_groups.json")))
+    case = cases.MODEL_CASES["micro2"]
+    cfg = case["cfg"]
+
+    def build():
+        return vit_models.VisionTransformerDiffPruning(img_size=cfg["img_size"], patch_size=cfg["patch"], embed_dim=cfg["dim"], depth=cfg["depth"],
+                                                       num_heads=cfg["heads"], mlp_ratio=cfg["mlp_ratio"], qkv_bias=True,
+                                                       num_classes=cfg["num_classes"], pruning_loc=list(cfg["pruning_loc"]),
+                                                       token_ratio=list(cfg["token_ratio"]), distill=True, topk_selection=True,
+                                                       predictor_loss_type="kl_div")
+    a = fx["args"]
+    args = types.SimpleNamespace(weight_decay=a["weight_decay"], lr=a["lr"], min_lr=a["min_lr"], epochs=a["epochs"],
+                                 warmup_steps=a["warmup_steps"], topk_selection=True, initial_sigma=a["initial_sigma"], early_exit=False)
+    # ---- host mirrors (utils.py)
+    m = build()
+    groups = utils.get_param_groups(m, args)
+    by_id = {id(p): n for n, p in m.named_parameters()}
+    for g in groups:
+        assert [by_id[id(p)] for p in g["params"]] == fx["groups"][g["name"]]["params"], g["name"]
+        assert g["weight_decay"] == fx["groups"][g["name"]]["weight_decay"]
+    for epoch, want in enumerate(fx["epochs"]):
+        utils.adjust_learning_rate(groups, args, epoch, m, warming_up_step=args.warmup_steps)
+        for g in groups:
+            if g["params"]:
+                assert abs(g["lr"] - want["lr"][g["name"]]) <= 1e-12, (epoch, g["name"])
+        assert sorted(n for n, p in m.named_parameters() if not p.requires_grad) == want["frozen"], epoch
+        assert abs(args.current_sigma - want["sigma"]) <= 1e-12
+    # ---- fused optimiser (d2s.engine): grouping by name and the same schedule
+    m = build()
+    for n, p in m.named_parameters():
+        g = engine._group_of(n, p)
+        expect = [k for k, v in fx["groups"].items() if n in v["params"]]
+        assert ([g] if g is not None else []) == expect, n
+
+    class Stub:
+        def set_lrs(self, predictor_lr, backbone_lr):
+            self.lrs = (predictor_lr, backbone_lr)
+    opt = Stub()
+    for epoch, want in enumerate(fx["epochs"]):
+        engine.adjust_learning_rate(opt, m, epoch, a["epochs"], a["lr"], a["min_lr"], a["warmup_steps"])
+        assert abs(opt.lrs[0] - want["lr"]["predictor"]) <= 1e-12 and abs(opt.lrs[1] - want["lr"]["base_decay"]) <= 1e-12, epoch
+        assert sorted(n for n, p in m.named_parameters() if not p.requires_grad) == want["frozen"], epoch

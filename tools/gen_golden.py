@@ -353,6 +353,40 @@ def gen_mask_loss_mse(losses):
     print("mask_loss_mse.npz loss", float(loss), sorted(metrics))
 
 
+def gen_param_groups(dv):
+    """Optimiser parameter groups and the per-epoch LR / freeze schedule of the reference (utils.py:66-147).  utils.py as a module
+    needs torchvision and the whole model zoo, so only its two function definitions are taken from its text (ast) and executed against
+    the reference's own student class; the fixture stores group membership by parameter name and, per epoch, the group learning
+    rates, every parameter's requires_grad flag and the top-k sigma."""
+    import ast
+    import contextlib
+    import io
+    import json
+    import math
+    tree = ast.parse(open(os.path.join(REF, "utils.py")).read())
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("get_param_groups", "adjust_learning_rate")]
+    assert len(fns) == 2
+    ns = {"math": math, "torch": torch}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "utils.py(two functions)", "exec"), ns)
+    case = cases.MODEL_CASES["micro2"]
+    student, _ = build_ref_models(dv, case)
+    args = _Args()
+    args.weight_decay, args.lr, args.min_lr, args.epochs, args.warmup_steps = 0.05, 5e-4, 1e-5, 10, 3
+    args.topk_selection, args.initial_sigma, args.early_exit = True, 0.05, False
+    groups = ns["get_param_groups"](student, args)
+    by_id = {id(p): n for n, p in student.named_parameters()}
+    out = {"args": {k: getattr(args, k) for k in ("weight_decay", "lr", "min_lr", "epochs", "warmup_steps", "initial_sigma")},
+           "groups": {g["name"]: {"weight_decay": g["weight_decay"], "params": [by_id[id(p)] for p in g["params"]]} for g in groups},
+           "epochs": []}
+    for epoch in range(args.epochs):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ns["adjust_learning_rate"](groups, args, epoch, student, warmup_predictor=False, warming_up_step=args.warmup_steps, base_multi=0.1)
+        out["epochs"].append({"lr": {g["name"]: g["lr"] for g in groups}, "sigma": args.current_sigma,
+                              "frozen": sorted(n for n, p in student.named_parameters() if not p.requires_grad)})
+    json.dump(out, open(os.path.join(OUT, "param_groups.json"), "w"), indent=1)
+    print("param_groups.json", {k: len(v["params"]) for k, v in out["groups"].items()}, [len(e["frozen"]) for e in out["epochs"]])
+
+
 def gen_checkpoint_ingestion(dv):
     """checkpoint_filter_fn / resize_pos_embed of the reference (dynamic_vit.py:1178-1213) on a synthetic DeiT-style checkpoint: a
     {'model': ...} wrapper, a patch projection stored as a matrix, and a 4x4-grid position table loaded into a 6x6-grid model."""
@@ -377,6 +411,7 @@ def main():
     gen_micro_intermediates(dv)
     gen_t2t()
     gen_checkpoint_ingestion(dv)
+    gen_param_groups(dv)
     gen_mask_loss_mse(losses)
     for name in cases.MODEL_CASES:
         gen_model_case(dv, losses, name)
