@@ -393,6 +393,26 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     __syncthreads();
     if (wave == 0 && n < N) part[(long)blockIdx.y * N + n] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
+// Fold of MANY partial rows (hundreds): 1024 threads = 16 columns x 64 partial-lanes, each thread adds every 64th partial of its
+// column (independent loads), LDS combines the 64 lane sums of a column in a fixed order.  grid = ceil(N / 16).
+__global__ __launch_bounds__(1024) void colsum_fold_wide_kernel(const float* __restrict__ part, int N, int slices, float* __restrict__ out,
+                                                                int accumulate) {
+    __shared__ float red[64][17];
+    const int col = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + col;
+    float s = 0.f;
+    if (n < N)
+        for (int z = kl; z < slices; z += 64) s += part[(long)z * N + n];
+    red[kl][col] = s;
+    __syncthreads();
+    if (kl == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) t += red[k][col];
+        out[n] = accumulate ? out[n] + t : t;
+    }
+}
+
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int N, int slices,
                                                            float* __restrict__ out, int accumulate) {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -446,7 +466,8 @@ namespace d2s_gemm {
 size_t split_workspace_bytes(int split, int M, int N, int K);
 int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace, size_t workspace_bytes, hipStream_t stream);
 size_t split_tn_pieces_bytes(int split, int M, int N, int K);
-int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_ws, hipStream_t stream);
+int split_tn_colsum_partials(int K);
+int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_ws, float* colsum_part, hipStream_t stream);
 }
 static int g_gemm_mode = 0;
 // Workgroups the wgrad launch aims for (tiles x K slices, rounded down): exactly 2 per CU.  Measured on the model's shapes
@@ -526,7 +547,7 @@ size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K) {
     const int slices = splitk_slices(tiles, K);
     size_t bytes = slices <= 1 ? 0 : ((size_t)slices * M * N + (size_t)slices * M) * sizeof(float);   // C slabs + fused bias-gradient slabs
     if (bf16_wgrad())   // + bf16 pieces of both operands + scratch of the separate bias-gradient pass (see gemm_impl)
-        bytes = ws_align(((size_t)(slices + 1) * M * N) * sizeof(float)) + ws_align(split_tn_pieces_bytes(1, M, N, K)) + d2s_colsum_workspace_bytes(K, M);
+        bytes = ws_align(((size_t)(slices + 1) * M * N) * sizeof(float)) + ws_align(split_tn_pieces_bytes(1, M, N, K)) + (size_t)split_tn_colsum_partials(K) * M * sizeof(float);
     return bytes;
 }
 
@@ -569,7 +590,7 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
         slices = (Kp + kper - 1) / kper;
         const size_t slab_bytes = ws_align(((size_t)(slices + 1) * M * N) * sizeof(float));
         const size_t piece_bytes = ws_align(split_tn_pieces_bytes(1, M, N, K));
-        const size_t cs_bytes = d2s_colsum_workspace_bytes(K, M);
+        const size_t cs_bytes = (size_t)split_tn_colsum_partials(K) * M * sizeof(float);
         if (!workspace || workspace_bytes < slab_bytes + piece_bytes + cs_bytes) return D2S_ERR_WORKSPACE;
         unsigned char* wsb = static_cast<unsigned char*>(workspace);
         p.k_per_slice = kper;
@@ -578,16 +599,16 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
         p.ldc = N;
         p.slab_stride = (long)M * N;
         p.remap_rows_per_img = 0;
-        int rc = launch_split_gemm_tn(p, 1, slices, wsb + slab_bytes, stream);
+        float* cs_part = colsum_out ? reinterpret_cast<float*>(wsb + slab_bytes + piece_bytes) : nullptr;
+        int rc = launch_split_gemm_tn(p, 1, slices, wsb + slab_bytes, cs_part, stream);
         if (rc != D2S_OK) return rc;
         const long total = (long)M * N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                            reinterpret_cast<const float*>(wsb), C, ldc, M, N, slices, (long)M * N, accumulate,
                            static_cast<const float*>(nullptr), static_cast<float*>(nullptr));
-        if (colsum_out) {
-            rc = d2s_colsum_f32(A, lda, K, M, colsum_out, accumulate, wsb + slab_bytes + piece_bytes, cs_bytes, stream);
-            if (rc != D2S_OK) return rc;
-        }
+        if (colsum_out)   // ordered fold of the per-64-token partials that the split pass of dy produced (exact fp32)
+            hipLaunchKernelGGL(colsum_fold_wide_kernel, dim3((M + 15) / 16), dim3(1024), 0, stream, cs_part, M, split_tn_colsum_partials(K),
+                               colsum_out, accumulate);
         return d2s_check_launch();
     }
     Tile tile = layout == 2 ? Tile{128, 128, 1.f} : pick_tile(M, N);

@@ -74,8 +74,9 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 // bytes per instruction.  LDS image [64 k][65]: the column walk of the store phase is at worst 2-way conflicted.
 template <int SPLIT>
 __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict__ src, long ld, __bf16* __restrict__ dst, int R, int K,
-                                                         int Kp, int vec) {
+                                                         int Kp, int vec, float* __restrict__ colsum_part) {
     __shared__ float t[64][65];
+    __shared__ float csum[4][64];
     const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64, tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                 // 64 k x 16 float4
@@ -95,6 +96,15 @@ __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict
         for (int j = 0; j < 4; ++j) t[k][r4 + j] = v[j];
     }
     __syncthreads();
+    if (colsum_part) {      // exact fp32 column sums over this block's 64 k (the bias gradient of the wgrad whose dy this is), all 256
+        const int c = tid & 63, q = tid >> 6;     // threads: 16 k per thread, then 4 partials per column; partial [blockIdx.y][R]
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sum += t[q * 16 + k][c];
+        csum[q][c] = sum;
+        __syncthreads();
+        if (tid < 64 && r0 + tid < R) colsum_part[(long)blockIdx.y * R + r0 + tid] = (csum[0][tid] + csum[1][tid]) + (csum[2][tid] + csum[3][tid]);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {                 // 64 rows x 8 chunks of 8 k
         const int f = tid + i * 256, c = f & 7, r = f >> 3;
@@ -373,11 +383,11 @@ int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace,
     const bool af32 = p.vecA && a_inkernel_env != 0;
     if (split == 3) {
         if (!af32) hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)((ea + 255) / 256)), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
-        if (b_cols) hipLaunchKernelGGL(split_cols_kernel<3>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
+        if (b_cols) hipLaunchKernelGGL(split_cols_kernel<3>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB, static_cast<float*>(nullptr));
         else hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)((eb + 255) / 256)), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
     } else {
         if (!af32) hipLaunchKernelGGL(split_rows_kernel<1>, dim3((unsigned)((ea + 255) / 256)), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
-        if (b_cols) hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
+        if (b_cols) hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB, static_cast<float*>(nullptr));
         else hipLaunchKernelGGL(split_rows_kernel<1>, dim3((unsigned)((eb + 255) / 256)), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
     }
     const int tiles = ((p.M + SBM - 1) / SBM) * ((p.N + SBN - 1) / SBN);
@@ -410,15 +420,18 @@ int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace,
 // The caller (gemm_f32.hip) combines the slabs in slab order.  Workspace: pieces only (the slabs are the caller's).
 size_t split_tn_pieces_bytes(int split, int M, int N, int K) { return split_workspace_bytes(split, M, N, K); }
 
-int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_ws, hipStream_t stream) {
+// colsum_part (optional, [split_tn_colsum_partials(K)][M] floats): per-64-token partial column sums of A (= dy), produced by the split
+// pass that reads dy anyway; the caller folds them in order into the bias gradient.
+int split_tn_colsum_partials(int K) { return (((K + 31) / 32) * 32 + 63) / 64; }
+int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_ws, float* colsum_part, hipStream_t stream) {
     const int Kp = ((p.K + 31) / 32) * 32;
     if (split != 1) return D2S_ERR_ARG;
     if ((long)p.M * Kp * 2 >= (1L << 32) || (long)p.N * Kp * 2 >= (1L << 32)) return D2S_ERR_ARG;
     __bf16* Ap = static_cast<__bf16*>(pieces_ws);
     __bf16* Bp = reinterpret_cast<__bf16*>(static_cast<unsigned char*>(pieces_ws) + align256((size_t)split * p.M * Kp * sizeof(__bf16)));
     dim3 block(256);
-    hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.M + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
-    hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
+    hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.M + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA, colsum_part);
+    hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB, static_cast<float*>(nullptr));
     const int tiles = ((p.M + SBM - 1) / SBM) * ((p.N + SBN - 1) / SBN);
     size_t lds = (size_t)split * (SBM + SBN) * (32 + 8) * sizeof(__bf16);
     if (lds < 4 * epi_stage_floats(2) * sizeof(float)) lds = 4 * epi_stage_floats(2) * sizeof(float);
