@@ -375,12 +375,15 @@ int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace,
     __bf16* Bp = reinterpret_cast<__bf16*>(static_cast<unsigned char*>(workspace) + align256((size_t)split * p.M * Kp * sizeof(__bf16)));
     const long ea = (long)p.M * (Kp / 4), eb = (long)p.N * (Kp / 4);
     dim3 block(256);
-    // Opt-in (D2S_SPLIT_A_INKERNEL=1): split the activation operand inside the matrix kernel (read as fp32 with 16-byte loads, no
-    // split pass over it).  Alone, a GEMM with <= 4 column tiles runs 9-12 % faster that way and one with 9-12 column tiles 4 %
-    // slower (each panel element is re-split per column tile); inside the training step the pre-split path is 0.5-1 % faster
-    // overall (the freshly written pieces are cache-hot), so it stays the default.
-    static const int a_inkernel_env = [] { const char* e = getenv("D2S_SPLIT_A_INKERNEL"); return e ? atoi(e) : 0; }();
-    const bool af32 = p.vecA && a_inkernel_env != 0;
+    // The activation operand can be converted inside the matrix kernel (read as fp32 with 16-byte loads, no split pass over it) instead
+    // of being pre-split.  bf16x3 (mode 1): alone, a GEMM with <= 4 column tiles runs 9-12 % faster that way and one with 9-12 column tiles
+    // 4 % slower (each panel element is re-split per column tile); inside the training step pre-splitting is 0.5-1 % faster overall, so
+    // it stays the default there.  bf16 (mode 2): the conversion is one instruction per two values; with at most 12 column tiles
+    // (every DeiT-S GEMM) in-kernel conversion wins (+2.7 % on the step), with 18-24 (DeiT-B qkv / fc1) the fp32 re-reads lose (-2.7 %).
+    // D2S_SPLIT_A_INKERNEL = 0 / 1 forces one or the other.
+    static const int a_inkernel_env = [] { const char* e = getenv("D2S_SPLIT_A_INKERNEL"); return e ? atoi(e) : -1; }();
+    const int col_tiles = (p.N + SBN - 1) / SBN;
+    const bool af32 = p.vecA && (a_inkernel_env >= 0 ? a_inkernel_env != 0 : (split == 1 && col_tiles <= 12));
     if (split == 3) {
         if (!af32) hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)((ea + 255) / 256)), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
         if (b_cols) hipLaunchKernelGGL(split_cols_kernel<3>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB, static_cast<float*>(nullptr));
