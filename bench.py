@@ -31,6 +31,14 @@ import torch
 import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 2:1-sparsity figure is never used)
+# per arithmetic mode: (kernel the GEMM work runs in, matrix instruction, peak the ALGORITHMIC 2MNK FLOPs are priced against)
+GEMM_MODE_ROOFLINE = {
+    "exact": ("gemm_f32_kernel", "v_mfma_f32_32x32x2_f32", PEAK_F32_MFMA_TFLOPS),
+    # bf16x3 split: 6 bf16 MFMAs per fp32-class product -> the algorithmic ceiling is a sixth of the bf16 peak
+    "split": ("gemm_pieces_nt_kernel<3 pieces>", "v_mfma_f32_32x32x16_bf16 x6 per product", PEAK_BF16_MFMA_TFLOPS / 6.0),
+    "bf16": ("gemm_pieces_nt_kernel<1 piece>", "v_mfma_f32_32x32x16_bf16", PEAK_BF16_MFMA_TFLOPS),
+}
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -48,6 +56,9 @@ def parse():
                     help="BASELINE.json config matrix: headline = DeiT-S keep 0.5 B=128 (the metric's config, default); c2 = DeiT-S keep 0.7 "
                          "B=128; c3 = DeiT-S 3-stage 0.7/0.5/0.3 B=32/GPU; c4 = T2T-ViT-14 keep 0.5 B=64/GPU; c5 = DeiT-B 384^2 keep 0.3 "
                          "bf16 GEMM operands B=64/GPU.  Non-headline presets skip the CPU baseline and set batch / keep / gemm mode.")
+    ap.add_argument("--reference-quirk", action="store_true",
+                    help="c5 only: keep int(196 * ratio) = 58 tokens of the 576 (the reference hard-codes init_n = 14*14, dynamic_vit.py:828,852) "
+                         "instead of int(576 * ratio) = 172")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented pass (no per-kernel figures in the line)")
     ap.add_argument("--time-kernels-in-region", action="store_true",
@@ -65,6 +76,9 @@ def parse():
     if a.config != "headline":
         a.no_cpu_baseline = True
         a.keep = a.keeps[0]
+    a.n_patches = (a.img // 16) ** 2
+    a.init_n = 196 if (a.reference_quirk or a.img == 224) else a.n_patches      # the count the keep ratios multiply
+    a.kept = [int(a.init_n * r) for r in a.keeps]
     return a
 
 
@@ -183,7 +197,7 @@ def hbm_copy_gbs(device, mbytes=1024, reps=10):
     return round(2.0 * a.numel() * reps / (s.elapsed_time(e) * 1e-3) / 1e9, 1)
 
 
-def build(device, keep, seed=0, arch="deit_small", locs=(3,), keeps=None, img=224):
+def build(device, keep, seed=0, arch="deit_small", locs=(3,), keeps=None, img=224, init_n=196):
     import vit_models
     torch.manual_seed(seed)
     keeps = list(keeps) if keeps else [keep]
@@ -193,7 +207,7 @@ def build(device, keep, seed=0, arch="deit_small", locs=(3,), keeps=None, img=22
     elif arch == "deit_base":
         geom = dict(img_size=img, patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True)
         student = vit_models.VisionTransformerDiffPruning(pruning_loc=list(locs), token_ratio=keeps, distill=True, topk_selection=True,
-                                                          predictor_loss_type="kl_div", **geom)
+                                                          predictor_loss_type="kl_div", init_n=init_n, **geom)
         teacher = vit_models.VisionTransformerTeacher(**geom)
     else:
         student = vit_models.dynamic_vit_small_patch16_224_student(list(locs), keeps, topk_selection=True, predictor_loss_type="kl_div")
@@ -319,7 +333,7 @@ def main():
     timer = KernelTimer()
     timer.wrap(ops)
 
-    student, teacher = build(device, args.keep, arch=args.arch, locs=args.locs, keeps=args.keeps, img=args.img)
+    student, teacher = build(device, args.keep, arch=args.arch, locs=args.locs, keeps=args.keeps, img=args.img, init_n=args.init_n)
     targs = types.SimpleNamespace(keep_ratios=list(args.keeps), mask_loss_type="kl_div", mixup=0.0, patch_score_threshold=None, step=0)
     ts = TrainStep(student, teacher, targs, lr=5e-4, min_lr=1e-5, weight_decay=0.05, epochs=25, warmup_steps=0,
                    distributed=distributed)
@@ -389,7 +403,9 @@ def main():
             "vs_baseline": None, "dtype": {"exact": "f32", "split": "f32 (bf16x3-split MFMA, fp32-class accuracy)", "bf16": "bf16 GEMM operands, f32 accumulate/elsewhere"}[args.gemm_mode], "data": "synthetic (N(0,1) images, uniform labels, random-init weights)",
             "config": {"workload": (f"DeiT-Small 224x224 patch16, 1-stage prune keep_ratio={args.keep} @ block 3 (196->{int(196 * args.keep)} tokens), "
                                     f"large LN predictor, kl_div mask loss, per-GPU batch {args.batch}") if args.config in ("headline", "c2") else
-                                   f"BASELINE config {args.config}: {args.arch} {args.img}x{args.img}, prune @ {args.locs} keep {args.keeps}, "
+                                   f"BASELINE config {args.config}: {args.arch} {args.img}x{args.img}, prune @ {args.locs} keep {args.keeps} "
+                                   f"({args.n_patches} -> {' -> '.join(str(k) for k in args.kept)} tokens; keep counts = int({args.init_n} * ratio)"
+                                   + (" - the reference's hard-coded init_n = 196 quirk" if args.init_n != args.n_patches else "") + "), "
                                    f"large LN predictor, kl_div mask loss, per-GPU batch {args.batch}",
                        "global_batch": args.batch * n_gpus, "parallelism": f"dp{n_gpus}", "final_loss": round(loss, 5)},
         }
@@ -405,9 +421,16 @@ def main():
             tot_fl = sum(v["work"] for v in gemms.values())
             dom = max(gemms, key=lambda k: gemms[k]["ms"])
             ach = gemms[dom]["work"] / (gemms[dom]["ms"] * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": f"gemm_f32_kernel<{dom[1]}> (v_mfma_f32_32x32x2_f32)",
-                                "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic({"NT": "gemm_f32_kernel<0, 0,", "NN": "gemm_f32_kernel<0, 1,", "TN": "gemm_f32_kernel<1, 1,"}[dom[1]]),
+            # the kernel, instruction and peak follow the arithmetic mode that actually ran (wgrad = the TN layout stays on the exact
+            # fp32 kernel in split mode)
+            mode_key = "exact" if (dom[1] == "TN" and args.gemm_mode == "split") else args.gemm_mode
+            kern, instr, peak = GEMM_MODE_ROOFLINE[mode_key]
+            assert ach <= peak, f"achieved {ach:.1f} TFLOP/s above the {peak} peak: wrong peak or wrong FLOP count"
+            pmc_prefix = {"NT": "gemm_f32_kernel<0, 0,", "NN": "gemm_f32_kernel<0, 1,", "TN": "gemm_f32_kernel<1, 1,"}[dom[1]] if mode_key == "exact" \
+                else "gemm_pieces_nt_kernel"
+            line["roofline"] = {"bound": "mfma", "kernel": f"{kern}, {dom[1]} layout ({instr})",
+                                "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                                "frac": round(ach / peak, 4), "traffic": pmc_traffic(pmc_prefix),
                                 "traffic_note": f"HBM bytes per launch, launch-weighted mean over this layout's tile-shape variants, from the committed PMC passes (profiles/{PMC_FILE}); not collected live",
                                 "avg_launch_us": round(1000.0 * gemms[dom]["ms"] / gemms[dom]["launches"], 2),
                                 "launches_per_step": gemms[dom]["launches"] / args.steps,

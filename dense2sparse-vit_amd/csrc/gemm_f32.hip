@@ -469,7 +469,6 @@ size_t split_tn_pieces_bytes(int split, int M, int N, int K);
 int split_tn_colsum_partials(int K);
 int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_ws, float* colsum_part, hipStream_t stream);
 }
-static int g_gemm_mode = 0;
 // Workgroups the wgrad launch aims for (tiles x K slices, rounded down): exactly 2 per CU.  Measured on the model's shapes
 // (tools/gemm_bench.py, D2S_SPLITK_TARGET sweep): 512 beats 768 / 1024 by 4-15 % (fewer, longer K slices: less slab traffic for the
 // ordered combine), and any count that is not a multiple of the CU count loses 10-40 % to imbalance.
@@ -486,9 +485,9 @@ static int splitk_target() {
 }
 static inline size_t ws_align(size_t x) { return (x + 255) & ~(size_t)255; }
 // mode 2 only: run the weight gradient on the bf16 matrix cores too (D2S_BF16_WGRAD=0 keeps it on the exact fp32 kernel)
-static bool bf16_wgrad() {
+static bool bf16_wgrad(int mode) {
     static const int on = [] { const char* e = getenv("D2S_BF16_WGRAD"); return e ? atoi(e) : 1; }();
-    return g_gemm_mode == 2 && on;
+    return mode == 2 && on;
 }
 extern "C" size_t d2s_colsum_workspace_bytes(int M, int N);
 extern "C" int d2s_colsum_f32(const float* X, long ldx, int M, int N, float* out, int accumulate, void* workspace,
@@ -529,15 +528,13 @@ extern "C" int d2s_debug_read_stamps_f32(unsigned long long* host_out, int n_wg)
 
 extern "C" {
 
-// Workspace needed by d2s_gemm_f32 for a given problem (only the TN / wgrad layout splits K).
-// 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  1: bf16x3 split on the bf16 matrix cores, fp32-class accuracy (gemm_split.hip).
+// Workspace needed by d2s_gemm_f32 for a given problem and arithmetic mode (pass the same mode to the query and to the call).
+// mode 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  1: bf16x3 split on the bf16 matrix cores, fp32-class accuracy (gemm_split.hip).
 // 2: bf16 operands, fp32 accumulation.  Modes 1 and 2 apply to the NT and NN layouts; in mode 2 wgrad (TN) also runs on the bf16
 // matrix cores (transposing split + K-sliced pieces kernel + the same ordered slab combine), in mode 1 it stays on the exact kernel.
-void d2s_set_gemm_mode(int mode) { g_gemm_mode = (mode == 1 || mode == 2) ? mode : 0; }
-int d2s_get_gemm_mode(void) { return g_gemm_mode; }
-
-size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K) {
-    if (layout != 2 && g_gemm_mode != 0) return split_workspace_bytes(g_gemm_mode == 1 ? 3 : 1, M, N, K);   // bf16 piece matrices
+// The mode is an argument of every call (no process-global state): a bf16 teacher can run beside an fp32 student, from any thread.
+size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K, int mode) {
+    if (layout != 2 && mode != 0) return split_workspace_bytes(mode == 1 ? 3 : 1, M, N, K);   // bf16 piece matrices
     if (layout != 2) {
         const Tile t = pick_tile(M, N);
         const int sl = nt_slices(((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn), K);
@@ -546,7 +543,7 @@ size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K) {
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     const int slices = splitk_slices(tiles, K);
     size_t bytes = slices <= 1 ? 0 : ((size_t)slices * M * N + (size_t)slices * M) * sizeof(float);   // C slabs + fused bias-gradient slabs
-    if (bf16_wgrad())   // + bf16 pieces of both operands + scratch of the separate bias-gradient pass (see gemm_impl)
+    if (bf16_wgrad(mode))   // + bf16 pieces of both operands + scratch of the separate bias-gradient pass (see gemm_impl)
         bytes = ws_align(((size_t)(slices + 1) * M * N) * sizeof(float)) + ws_align(split_tn_pieces_bytes(1, M, N, K)) + (size_t)split_tn_colsum_partials(K) * M * sizeof(float);
     return bytes;
 }
@@ -556,8 +553,8 @@ size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K) {
 static int gemm_impl(int layout, const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                      int K, int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, int aux_rows,
                      int remap_rows_per_img, int remap_skip, int accumulate, void* workspace, size_t workspace_bytes,
-                     hipStream_t stream, float* colsum_out) {
-    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || layout < 0 || layout > 2) return D2S_ERR_ARG;
+                     hipStream_t stream, float* colsum_out, int mode) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || layout < 0 || layout > 2 || mode < 0 || mode > 2) return D2S_ERR_ARG;
     if ((epilogue == EPI_BIAS_RESID || epilogue == EPI_MUL_GELU_GRAD || epilogue == EPI_MUL_RELU_MASK ||
          epilogue == EPI_BIAS_ROWADD) && !aux)
         return D2S_ERR_ARG;
@@ -574,13 +571,13 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
     const int alay = layout == 2 ? 1 : 0, blay = layout == 0 ? 0 : 1;
     p.vecA = aligned16(A) && (lda % 4 == 0) && (alay == 0 ? (K % 4 == 0) : (M % 4 == 0));
     p.vecB = aligned16(B) && (ldb % 4 == 0) && (blay == 0 ? (K % 4 == 0) : (N % 4 == 0));
-    if (g_gemm_mode != 0 && layout != 2) {
+    if (mode != 0 && layout != 2) {
         if (accumulate) p.epi = EPI_ACCUM;
         p.k_per_slice = K;
         p.slab_stride = 0;
-        return launch_split_gemm(p, layout == 1 ? 1 : 0, g_gemm_mode == 1 ? 3 : 1, workspace, workspace_bytes, stream);
+        return launch_split_gemm(p, layout == 1 ? 1 : 0, mode == 1 ? 3 : 1, workspace, workspace_bytes, stream);
     }
-    if (layout == 2 && bf16_wgrad()) {
+    if (layout == 2 && bf16_wgrad(mode)) {
         // wgrad in bf16 mode: transposing split of dy and x into K-contiguous bf16 pieces, K-sliced pieces kernel into fp32 slabs,
         // the same ordered slab combine as the exact path; the bias gradient is a separate exact fp32 column-sum pass over dy.
         const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
@@ -674,21 +671,21 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
 
 int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                  int K, int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, int aux_rows,
-                 int remap_rows_per_img, int remap_skip, int accumulate, void* workspace, size_t workspace_bytes,
+                 int remap_rows_per_img, int remap_skip, int accumulate, int mode, void* workspace, size_t workspace_bytes,
                  hipStream_t stream) {
     return gemm_impl(layout, A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, aux, ldaux, aux_out, aux_rows, remap_rows_per_img,
-                     remap_skip, accumulate, workspace, workspace_bytes, stream, nullptr);
+                     remap_skip, accumulate, workspace, workspace_bytes, stream, nullptr, mode);
 }
 
 // nn.Linear backward w.r.t. its parameters in one pass over dy:  dW[n_out, n_in] (+)= dy^T x,  db[n_out] (+)= column sums of dy.
 // The bias gradient is folded out of the dy tiles the GEMM streams through its registers anyway (no second read of dy).
-size_t d2s_linear_wgrad_workspace_bytes(int tokens, int n_out, int n_in) {
-    return d2s_gemm_f32_workspace_bytes(2, n_out, n_in, tokens);
+size_t d2s_linear_wgrad_workspace_bytes(int tokens, int n_out, int n_in, int mode) {
+    return d2s_gemm_f32_workspace_bytes(2, n_out, n_in, tokens, mode);
 }
 int d2s_linear_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, float* db, int tokens,
-                         int n_out, int n_in, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                         int n_out, int n_in, int accumulate, int mode, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     return gemm_impl(2, dy, lddy, x, ldx, dW, lddw, n_out, n_in, tokens, EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0,
-                     accumulate, workspace, workspace_bytes, stream, db);
+                     accumulate, workspace, workspace_bytes, stream, db, mode);
 }
 
 size_t d2s_colsum_workspace_bytes(int M, int N) {

@@ -224,9 +224,25 @@ constexpr int CH = 1024;
 struct ChunkDesc { float lr, wd; int active; int pad; };
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, const ChunkDesc* __restrict__ desc, float b1, float b2,
-                                                    float eps, float bc1, float bc2_sqrt, float grad_scale) {
+                                                    float eps, float bc1, float bc2_sqrt, float grad_scale,
+                                                    int* __restrict__ chunk_steps) {
     const ChunkDesc d = desc[blockIdx.x];
     if (!d.active) return;
+    // torch.optim.AdamW keeps state['step'] PER PARAMETER and only advances it when the parameter has a gradient: a tensor that was
+    // frozen during the warm-up epochs starts its bias correction at t = 1 when it is first updated.  chunk_steps[c] is that counter
+    // for the tensor chunk c belongs to (advanced here, for active chunks only); without it the global step is used for every chunk.
+    if (chunk_steps) {
+        __shared__ float bc[2];
+        const int t = chunk_steps[blockIdx.x] + 1;
+        if (threadIdx.x == 0) {
+            bc[0] = (float)(1.0 - pow((double)b1, (double)t));
+            bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+        }
+        __syncthreads();    // every thread has read the old counter before thread 0 replaces it
+        bc1 = bc[0];
+        bc2_sqrt = bc[1];
+        if (threadIdx.x == 0) chunk_steps[blockIdx.x] = t;
+    }
     const long base = (long)blockIdx.x * CH + threadIdx.x * 4;
     f32x4 pv = *reinterpret_cast<f32x4*>(p + base);
     const f32x4 gv = *reinterpret_cast<const f32x4*>(g + base);
@@ -311,14 +327,15 @@ int d2s_act_grad(const float* g, const float* z, float* out, long n, int kind, h
 int d2s_adamw_chunk_elems() { return CH; }
 
 // params / grads / exp_avg / exp_avg_sq: flat arenas of n_chunks * 1024 floats; desc: n_chunks x {float lr, float wd,
-// int active, int pad} in device memory.  step >= 1 (bias corrections computed on the host).
+// int active, int pad} in device memory.  chunk_steps: n_chunks ints in device memory, the per-tensor update counters of
+// torch.optim.AdamW (state['step']), advanced by this call for the active chunks; null: `step` >= 1 is used for every chunk.
 int d2s_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const void* desc, int n_chunks, float beta1,
-                   float beta2, float eps, int step, float grad_scale, hipStream_t stream) {
-    if (!params || !grads || !exp_avg || !exp_avg_sq || !desc || n_chunks <= 0 || step < 1) return D2S_ERR_ARG;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+                   float beta2, float eps, int step, float grad_scale, int* chunk_steps, hipStream_t stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !desc || n_chunks <= 0 || (!chunk_steps && step < 1)) return D2S_ERR_ARG;
+    const double bc1 = chunk_steps ? 1.0 : 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = chunk_steps ? 1.0 : 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq,
-                       static_cast<const ChunkDesc*>(desc), beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+                       static_cast<const ChunkDesc*>(desc), beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale, chunk_steps);
     return d2s_check_launch();
 }
 

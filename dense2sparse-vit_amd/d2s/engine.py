@@ -67,6 +67,14 @@ class ParamArena:
         o = self.offsets[i]
         return o // self.chunk, (o + ((self.sizes[i] + self.chunk - 1) // self.chunk) * self.chunk) // self.chunk
 
+    def check_alias(self):
+        """The optimiser updates the arena; a parameter whose .data was re-assigned afterwards (.to(), .half(), load into a new
+        tensor) would silently stop following it."""
+        base = self.params.data_ptr()
+        for n, p, o in zip(self.names, self.params_list, self.offsets):
+            if p.data_ptr() != base + 4 * o:
+                raise lib.D2SError(f"parameter {n} no longer aliases the parameter arena (re-assigned after TrainStep was built)")
+
     def collect_grads(self):
         """Make sure every live gradient sits in the arena (it does when the Functions produced it; a gradient that
         autograd materialised elsewhere is copied in) and detach .grad from autograd's bookkeeping."""
@@ -87,6 +95,9 @@ class FusedAdamW:
         self.group_lr = {"predictor": lr, "base_no_decay": lr, "base_decay": lr, "early_exit": lr}
         self.group_wd = {"predictor": weight_decay, "base_no_decay": 0.0, "base_decay": weight_decay, "early_exit": weight_decay}
         self.steps = 0
+        # torch.optim.AdamW counts updates per parameter (state['step'] advances only when the parameter has a gradient), so a tensor
+        # frozen during the warm-up epochs starts its bias correction at t = 1 afterwards: one counter per arena chunk, on the device
+        self.chunk_steps = torch.zeros(arena.n_chunks, dtype=torch.int32, device=arena.params.device)
         self._desc = None
         self._dirty = True
 
@@ -117,7 +128,7 @@ class FusedAdamW:
         self.steps += 1
         a = self.arena
         ops.adamw_step(a.params, a.grads, self.exp_avg, self.exp_avg_sq, self._desc, a.n_chunks, self.betas[0], self.betas[1],
-                       self.eps, self.steps, grad_scale)
+                       self.eps, self.steps, grad_scale, chunk_steps=self.chunk_steps)
 
     def zero_grad(self):
         for p in self.arena.params_list:
@@ -177,14 +188,40 @@ class GradReducer:
         self.stream = torch.cuda.Stream() if arena.params.is_cuda else None
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self._hi = arena.total
+        # arena ranges [lo, hi) whose gradients exist this epoch (ascending, merged); None = the whole arena.  requires_grad flips
+        # between epochs (utils.py:112-147): in the warm-up epochs only the predictors train, and cls_token / pos_embed are never
+        # optimised (utils.py:79-80), so their slices are not exchanged either (set_live_ranges, called from TrainStep.set_epoch)
+        self.live = None
         self.force = False      # rehearsal: issue the collectives even with a single rank
         self.timing = False     # bench: bracket every collective with events on the side stream
         self._events, self._exposed, self._bytes, self._launched = [], [], 0, False
+
+    def set_live_ranges(self, ranges):
+        """ranges: iterable of (lo, hi) arena offsets holding live gradients; merged when they touch."""
+        merged = []
+        for lo, hi in sorted(ranges):
+            if merged and lo <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], hi)
+            elif hi > lo:
+                merged.append([lo, hi])
+        self.live = [tuple(r) for r in merged]
+
+    def live_elems(self):
+        return self.arena.total if self.live is None else sum(hi - lo for lo, hi in self.live)
 
     def _launch(self, lo):
         hi, self._hi = self._hi, lo
         if (self.world == 1 and not self.force) or lo >= hi:
             return
+        if self.live is None:
+            self._reduce(lo, hi)
+        else:       # only the parts of [lo, hi) that hold live gradients, from the arena's end towards its start
+            for a, b in reversed(self.live):
+                a, b = max(a, lo), min(b, hi)
+                if b > a:
+                    self._reduce(a, b)
+
+    def _reduce(self, lo, hi):
         buf = self.arena.grads[lo:hi]
         self._launched = True
         if self.stream is None:          # CPU tensors (gloo rehearsal): blocking
@@ -203,8 +240,13 @@ class GradReducer:
 
     def ready_from(self, lo):
         """Every gradient at arena offset >= lo is final."""
-        if self._hi - lo >= self.bucket_elems:
+        if self._pending(lo) >= self.bucket_elems:
             self._launch(lo)
+
+    def _pending(self, lo):
+        if self.live is None:
+            return self._hi - lo
+        return sum(max(0, min(b, self._hi) - max(a, lo)) for a, b in self.live)
 
     def finish(self):
         """Flush the remainder, join, and return 1/world (folded into the optimiser's gradient scale)."""
@@ -269,7 +311,15 @@ class TrainStep:
     def set_epoch(self, epoch):
         self.epoch = epoch
         self.args.step = epoch
-        return adjust_learning_rate(self.opt, self.student, epoch, self.epochs, self.lr, self.min_lr, self.warmup_steps, self.frozen)
+        out = adjust_learning_rate(self.opt, self.student, epoch, self.epochs, self.lr, self.min_lr, self.warmup_steps, self.frozen)
+        if self.reducer is not None:       # the live gradient set changed: rebuild the bucket plan (SURVEY 8e caveat ii)
+            a = self.arena
+            chunk = a.chunk
+            self.reducer.set_live_ranges(
+                (o, o + ((sz + chunk - 1) // chunk) * chunk)
+                for o, sz, p, g in zip(a.offsets, a.sizes, a.params_list, self.opt.groups)
+                if p.requires_grad and g is not None and g != "early_exit")
+        return out
 
     def forward_losses(self, images, labels):
         if self._teacher_stream is not None:
@@ -283,9 +333,11 @@ class TrainStep:
             logits_s, token_s, pred_logits, kept = self.student(images)
             main.wait_stream(side)
         else:
-            with torch.no_grad():
-                logits_t, token_t, cls_attn = self.teacher(images)
-            logits_s, token_s, pred_logits, kept = self.student(images)
+            from .functional import shared_patch_columns
+            with shared_patch_columns():       # teacher and student embed the same images: one im2col pass for both
+                with torch.no_grad():
+                    logits_t, token_t, cls_attn = self.teacher(images)
+                logits_s, token_s, pred_logits, kept = self.student(images)
         mask_loss = self.mask_loss_fn(pred_logits, cls_attn, kept, self.metrics)
         backbone_loss = self.backbone_loss_fn(logits_s, token_s, logits_t, token_t, kept, labels, self.metrics)
         loss = mask_loss if self.epoch < self.warmup_steps else backbone_loss + mask_loss     # train.py:50-53
@@ -293,6 +345,7 @@ class TrainStep:
                           pred_logits=pred_logits, logits_t=logits_t, token_t=token_t, cls_attn=cls_attn)
 
     def __call__(self, images, labels):
+        self.arena.check_alias()
         self.student.train()
         loss, info = self.forward_losses(images, labels)
         self.opt.zero_grad()

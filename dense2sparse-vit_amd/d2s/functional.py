@@ -8,6 +8,8 @@ Reference lines (relative to /root/reference):
   GatherFn     vit_models/dynamic_vit.py:907-912
   HeadFn       vit_models/dynamic_vit.py:993-1006
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -23,6 +25,55 @@ def _need(ctx, i):
     return ctx.needs_input_grad[i]
 
 
+def mode_recorded(cls):
+    """Class decorator for Functions that launch GEMM / attention kernels: the forward records the arithmetic mode it ran in
+    (ops.get_gemm_mode(): the process default or the caller's `with ops.gemm_mode(...)`), the backward - which autograd runs on its
+    own thread, outside the caller's block - re-enters it, so forward and backward of one module always use the same arithmetic."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args):
+        ctx.gmode = ops.get_gemm_mode()
+        return fwd(ctx, *args)
+
+    def backward(ctx, *grads):
+        with ops.gemm_mode(ctx.gmode):
+            return bwd(ctx, *grads)
+
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
+# Teacher and student embed the SAME image batch (train.py:40,43): inside `shared_patch_columns()` the im2col matrix of an image
+# tensor is built once and handed to every EmbedFn that asks for it (same tensor object, same version counter, same patch size,
+# same stream).  The block is what bounds the cache's lifetime - nothing is kept once it exits.
+_COLS = {"depth": 0, "entry": None}
+
+
+class shared_patch_columns:
+    def __enter__(self):
+        _COLS["depth"] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _COLS["depth"] -= 1
+        if _COLS["depth"] == 0:
+            _COLS["entry"] = None
+        return False
+
+
+def _patch_columns(img, patch):
+    if _COLS["depth"] == 0:
+        return ops.im2col_patch(img, patch)
+    stream = torch.cuda.current_stream(img.device).cuda_stream
+    ent = _COLS["entry"]
+    if ent is not None and ent[0]() is img and ent[1:4] == (img._version, patch, stream):
+        return ent[4]
+    col = ops.im2col_patch(img, patch)
+    _COLS["entry"] = (weakref.ref(img), img._version, patch, stream, col)
+    return col
+
+
+@mode_recorded
 class EmbedFn(torch.autograd.Function):
     """img [B,3,H,W] -> tokens [B, T+1, D]  (conv-as-GEMM with the bias + pos_embed add fused in the epilogue)."""
 
@@ -30,7 +81,7 @@ class EmbedFn(torch.autograd.Function):
     def forward(ctx, img, proj_w, proj_b, cls_token, pos_embed, patch):
         B = img.shape[0]
         D = proj_w.shape[0]
-        col = ops.im2col_patch(img.contiguous(), patch)
+        col = _patch_columns(img.contiguous(), patch)
         T = col.shape[0] // B
         Kc = col.shape[1]
         tokens = torch.empty((B, T + 1, D), dtype=torch.float32, device=img.device)
@@ -38,8 +89,9 @@ class EmbedFn(torch.autograd.Function):
         pos = pos_embed.reshape(T + 1, D)
         ops.gemm(ops.NT, col, Kc, w2, Kc, tokens, D, B * T, D, Kc, ops.EPI_BIAS_ROWADD, proj_b, pos[1:], D, None, T, T, 1)
         ops.fill_cls(cls_token.reshape(D), pos, tokens)
-        ctx.save_for_backward(col, proj_w, proj_b, cls_token, pos_embed)
-        ctx.dims = (B, T, D, Kc, tuple(proj_w.shape))
+        if any(ctx.needs_input_grad):       # forward-only callers (frozen teacher, eval) keep nothing
+            ctx.save_for_backward(col, proj_w, proj_b, cls_token, pos_embed)
+            ctx.dims = (B, T, D, Kc, tuple(proj_w.shape))
         return tokens
 
     @staticmethod
@@ -66,16 +118,32 @@ class EmbedFn(torch.autograd.Function):
         return None, dw, db, dcls, dpos, None
 
 
+@mode_recorded
 class BlockFn(torch.autograd.Function):
     """One pre-norm transformer block on a packed [B, n, D] token tensor; also returns the CLS row of the softmax."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, heads, eps, want_cls):
+    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, heads, eps, want_cls, scale):
         B, n, D = x.shape
         M = B * n
         x = x.contiguous()
-        scale = float(_DH) ** -0.5
+        scale = float(_DH) ** -0.5 if scale is None else float(scale)     # Attention.scale = qk_scale or head_dim ** -0.5 (:188)
         cmap = ops.contiguous_map(M, D)
+        if not any(ctx.needs_input_grad):
+            # forward-only (the frozen teacher under no_grad, eval): no LayerNorm statistics, no GELU pre-activation copy (155 MB per
+            # block at B=128), nothing saved
+            ln1, _, _ = ops.layernorm_fwd(x, cmap, n1w, n1b, M, D, eps, stats=False)
+            qkv = ops.linear_fwd(ln1, qkvw, qkvb)
+            del ln1
+            ao, _, cls_row = ops.attn_fwd(qkv, B, n, heads, scale, want_cls)
+            del qkv
+            x1 = ops.linear_fwd(ao, projw, projb, epi=ops.EPI_BIAS_RESID, aux=x.view(M, D))
+            ln2, _, _ = ops.layernorm_fwd(x1, cmap, n2w, n2b, M, D, eps, stats=False)
+            h = ops.linear_fwd(ln2, fc1w, fc1b, epi=ops.EPI_BIAS_GELU)
+            y = ops.linear_fwd(h, fc2w, fc2b, epi=ops.EPI_BIAS_RESID, aux=x1)
+            if cls_row is None:
+                cls_row = torch.empty((0,), device=x.device)
+            return y.view(B, n, D), cls_row
         ln1, mean1, rstd1 = ops.layernorm_fwd(x, cmap, n1w, n1b, M, D, eps)
         qkv = ops.linear_fwd(ln1, qkvw, qkvb)
         ao, lse, cls_row = ops.attn_fwd(qkv, B, n, heads, scale, want_cls)
@@ -133,9 +201,10 @@ class BlockFn(torch.autograd.Function):
             grads[1], grads[2] = (dn1w if wants[1] else None), (dn1b if wants[2] else None)
             gx = gx.view(B, n, D) if wants[0] else None
         grads[0] = gx
-        return tuple(grads) + (None, None, None)
+        return tuple(grads) + (None, None, None, None)
 
 
+@mode_recorded
 class PredictorFn(torch.autograd.Function):
     """Large LayerNorm predictor (PredictorLG, topk_selection=True) on x[:, 1:] of a [B, n, D] tensor.
     Returns (scores [B, n-1] differentiable, keep_probs [B, n-1] non-differentiable)."""
@@ -148,7 +217,8 @@ class PredictorFn(torch.autograd.Function):
         M = B * T
         x = x.contiguous()
         eps = 1e-5
-        h0, mean0, rstd0 = ops.layernorm_fwd(x, ops.skip_cls_map(n, D), params[0], params[1], M, D, eps)
+        train = any(ctx.needs_input_grad)
+        h0, mean0, rstd0 = ops.layernorm_fwd(x, ops.skip_cls_map(n, D), params[0], params[1], M, D, eps, stats=train)
         a1 = ops.linear_fwd(h0, params[2], params[3], epi=ops.EPI_BIAS_RELU)
         C = a1.shape[1]
         cur = ops.half_mean_concat(a1, B, T, C)
@@ -157,15 +227,16 @@ class PredictorFn(torch.autograd.Function):
         for j in range(nl):
             lw, lb, fw, fb = params[4 + 4 * j: 8 + 4 * j]
             width = cur.shape[1]
-            ln, mean, rstd = ops.layernorm_fwd(cur, ops.contiguous_map(M, width), lw, lb, M, width, eps)
+            ln, mean, rstd = ops.layernorm_fwd(cur, ops.contiguous_map(M, width), lw, lb, M, width, eps, stats=train)
             last = j == nl - 1
             nxt = ops.linear_fwd(ln, fw, fb, epi=ops.EPI_BIAS if last else ops.EPI_BIAS_RELU)
             saved += [cur, ln, mean, rstd]
             cur = nxt
         scores = cur.view(B, T)
         probs = ops.softmax_rows(scores)
-        ctx.save_for_backward(*saved, *params)
-        ctx.meta = (B, n, D, T, M, C, nl, len(saved))
+        if train:
+            ctx.save_for_backward(*saved, *params)
+            ctx.meta = (B, n, D, T, M, C, nl, len(saved))
         ctx.mark_non_differentiable(probs)
         return scores, probs
 
@@ -227,6 +298,7 @@ class GatherFn(torch.autograd.Function):
         return ops.scatter_unpack(g.contiguous(), kept, ctx.n), None
 
 
+@mode_recorded
 class HeadFn(torch.autograd.Function):
     """Final LayerNorm + classifier head on the CLS row.  Returns (logits [B,C], features = normed tokens[:, 1:])."""
 
@@ -235,12 +307,14 @@ class HeadFn(torch.autograd.Function):
         B, n, D = x.shape
         M = B * n
         x = x.contiguous()
-        xn, mean, rstd = ops.layernorm_fwd(x, ops.contiguous_map(M, D), nw, nb, M, D, eps)
+        train = any(ctx.needs_input_grad)
+        xn, mean, rstd = ops.layernorm_fwd(x, ops.contiguous_map(M, D), nw, nb, M, D, eps, stats=train)
         C = hw.shape[0]
         logits = torch.empty((B, C), dtype=torch.float32, device=x.device)
         ops.gemm(ops.NT, xn, n * D, hw, D, logits, C, B, C, D, ops.EPI_BIAS, hb)   # A = CLS rows (row stride n*D)
-        ctx.save_for_backward(x, nw, hw, mean, rstd, xn, nb, hb)
-        ctx.dims = (B, n, D, C)
+        if train:
+            ctx.save_for_backward(x, nw, hw, mean, rstd, xn, nb, hb)
+            ctx.dims = (B, n, D, C)
         return logits, xn.view(B, n, D)[:, 1:]
 
     @staticmethod
@@ -367,6 +441,7 @@ def select_topk(keep_probs, k):
     return ops.select_topk(keep_probs.detach().contiguous(), k)
 
 
+@mode_recorded
 class LinearFn(torch.autograd.Function):
     """y = act(x W^T + b) for the stand-alone Mlp / Attention modules (act: None | "gelu" | "relu")."""
 
@@ -404,6 +479,7 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+@mode_recorded
 class AttnCoreFn(torch.autograd.Function):
     """softmax(q k^T / sqrt(dh)) v on the raw qkv Linear output [B*n, 3*H*64] (+ CLS softmax row)."""
 

@@ -6,8 +6,10 @@ synchronisation: SURVEY 8e caveat i)."""
 import torch
 
 from . import ops
+from .functional import mode_recorded
 
 
+@mode_recorded
 class PredictorBNFn(torch.autograd.Function):
     """forward(x [B, n, D], training, n_layers running_mean..., running_var..., params...) -> (scores [B, n-1], keep_probs [B, n-1]).
     params: in_bn_w, in_bn_b, in_fc_w, in_fc_b, then 5 x (bn_w, bn_b, fc_w, fc_b); running: 6 x (mean, var) buffers."""

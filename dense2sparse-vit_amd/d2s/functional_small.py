@@ -4,8 +4,10 @@ d2s.functional.PredictorFn with exact-erf GELU (pre-activations are saved, the G
 import torch
 
 from . import ops
+from .functional import mode_recorded
 
 
+@mode_recorded
 class SmallPredictorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, *params):

@@ -10,6 +10,7 @@ Reference lines (relative to /root/reference/vit_models):
 import torch
 
 from . import ops
+from .functional import mode_recorded
 
 
 def _need(ctx, i):
@@ -94,6 +95,7 @@ def _mlp_tail_bwd(gout, y, saved, n2w, n2b, f1w, f1b, f2w, f2b, want):
     return gy, grads
 
 
+@mode_recorded
 class TokenPerformerFn(torch.autograd.Function):
     """Token_performer.forward on [B, T, dim]: LN -> kqv -> FAVOR+ attention -> v + proj -> LN -> MLP + residual."""
 
@@ -140,6 +142,7 @@ class TokenPerformerFn(torch.autograd.Function):
         return tuple(grads)
 
 
+@mode_recorded
 class TokenTransformerFn(torch.autograd.Function):
     """Token_transformer.forward on [B, T, dim]: LN -> qkv (1 head of width 64, scale dim**-0.5) -> fused attention ->
     v + proj -> LN -> MLP + residual."""

@@ -16,12 +16,10 @@ P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ct
 
 # name -> (restype, [argtypes]); the trailing hipStream_t is appended automatically for int-returning entries
 _SIGS = {
-    "d2s_set_gemm_mode": (None, [I]),
-    "d2s_get_gemm_mode": (I, None),
-    "d2s_gemm_f32_workspace_bytes": (Z, [I, I, I, I]),
-    "d2s_gemm_f32": (I, [I, P, L, P, L, P, L, I, I, I, I, P, P, L, P, I, I, I, I, P, Z]),
-    "d2s_linear_wgrad_workspace_bytes": (Z, [I, I, I]),
-    "d2s_linear_wgrad_f32": (I, [P, L, P, L, P, L, P, I, I, I, I, P, Z]),
+    "d2s_gemm_f32_workspace_bytes": (Z, [I, I, I, I, I]),
+    "d2s_gemm_f32": (I, [I, P, L, P, L, P, L, I, I, I, I, P, P, L, P, I, I, I, I, I, P, Z]),
+    "d2s_linear_wgrad_workspace_bytes": (Z, [I, I, I, I]),
+    "d2s_linear_wgrad_f32": (I, [P, L, P, L, P, L, P, I, I, I, I, I, P, Z]),
     "d2s_batchnorm_workspace_bytes": (Z, [L, I]),
     "d2s_batchnorm_fwd": (I, [P, P, P, P, P, P, P, P, L, I, F, F, I, P, Z]),
     "d2s_batchnorm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, L, I, P, Z]),
@@ -63,7 +61,7 @@ _SIGS = {
     "d2s_perturbed_topk_fwd": (I, [P, P, P, I, I, I, I, F, P, Z]),
     "d2s_perturbed_topk_bwd": (I, [P, P, P, P, I, I, I, I, F]),
     "d2s_adamw_chunk_elems": (I, None),
-    "d2s_adamw_step": (I, [P, P, P, P, P, I, F, F, F, I, F]),
+    "d2s_adamw_step": (I, [P, P, P, P, P, I, F, F, F, I, F, P]),
 }
 
 _lib = None

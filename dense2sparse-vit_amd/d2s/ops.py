@@ -3,6 +3,7 @@
 Conventions: fp32 contiguous device tensors unless a row map says otherwise; 2-D views [rows, features].
 """
 import os
+import threading
 
 import torch
 
@@ -34,10 +35,11 @@ def _f32(t):
 
 def gemm(layout, A, lda, B, ldb, C, ldc, M, N, K, epi=EPI_NONE, bias=None, aux=None, ldaux=0, aux_out=None, aux_rows=0,
          remap_rows=0, remap_skip=0, accumulate=False):
-    need = lib.query("d2s_gemm_f32_workspace_bytes", layout, M, N, K)
+    mode = get_gemm_mode()
+    need = lib.query("d2s_gemm_f32_workspace_bytes", layout, M, N, K, mode)
     ws = workspace(need, C.device) if need else None
     lib.call("d2s_gemm_f32", layout, lib.ptr(A), lda, lib.ptr(B), ldb, lib.ptr(C), ldc, M, N, K, epi, lib.ptr(bias),
-             lib.ptr(aux), ldaux, lib.ptr(aux_out), aux_rows, remap_rows, remap_skip, int(accumulate), lib.ptr(ws),
+             lib.ptr(aux), ldaux, lib.ptr(aux_out), aux_rows, remap_rows, remap_skip, int(accumulate), mode, lib.ptr(ws),
              ws.numel() if ws is not None else 0)
     return C
 
@@ -69,9 +71,10 @@ def linear_wgrad(dy, x, dW, accumulate=False, db=None):
     _f32(dy), _f32(x), _f32(dW)
     M, N = dy.shape
     K = x.shape[1]
-    need = lib.query("d2s_linear_wgrad_workspace_bytes", M, N, K)
+    mode = get_gemm_mode()
+    need = lib.query("d2s_linear_wgrad_workspace_bytes", M, N, K, mode)
     ws = workspace(need, dW.device) if need else None
-    lib.call("d2s_linear_wgrad_f32", lib.ptr(dy), N, lib.ptr(x), K, lib.ptr(dW), K, lib.ptr(db), M, N, K, int(accumulate),
+    lib.call("d2s_linear_wgrad_f32", lib.ptr(dy), N, lib.ptr(x), K, lib.ptr(dW), K, lib.ptr(db), M, N, K, int(accumulate), mode,
              lib.ptr(ws), ws.numel() if ws is not None else 0)
     return dW
 
@@ -105,10 +108,11 @@ def skip_cls_map(n, D):
     return (n - 1, n * D, D, D)
 
 
-def layernorm_fwd(x, rowmap, w, b, rows, D, eps):
+def layernorm_fwd(x, rowmap, w, b, rows, D, eps, stats=True):
+    """stats=False (forward-only callers: the frozen teacher, eval): the per-row mean / rstd are not written."""
     y = torch.empty((rows, D), dtype=torch.float32, device=x.device)
-    mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
-    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device) if stats else None
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device) if stats else None
     lib.call("d2s_layernorm_fwd", lib.ptr(x), *rowmap, lib.ptr(w), lib.ptr(b), lib.ptr(y), lib.ptr(mean), lib.ptr(rstd),
              rows, D, float(eps))
     return y, mean, rstd
@@ -340,39 +344,81 @@ def perturbed_topk_bwd(x, noise, g, k, sigma):
     return gx
 
 
-def adamw_step(params, grads, exp_avg, exp_avg_sq, desc, n_chunks, beta1, beta2, eps, step, grad_scale=1.0):
+def adamw_step(params, grads, exp_avg, exp_avg_sq, desc, n_chunks, beta1, beta2, eps, step, grad_scale=1.0, chunk_steps=None):
+    """chunk_steps: int32 [n_chunks] per-tensor update counters (torch.optim.AdamW's state['step']), advanced in place."""
+    assert chunk_steps is None or (chunk_steps.dtype == torch.int32 and chunk_steps.numel() == n_chunks)
     lib.call("d2s_adamw_step", lib.ptr(params), lib.ptr(grads), lib.ptr(exp_avg), lib.ptr(exp_avg_sq), lib.ptr(desc), n_chunks,
-             float(beta1), float(beta2), float(eps), int(step), float(grad_scale))
+             float(beta1), float(beta2), float(eps), int(step), float(grad_scale), lib.ptr(chunk_steps))
 
 
-# ---- gradient-arena registry: parameter storage address -> (flat gradient arena, offset, numel, shape) ----
-_GRAD_BUFFERS = {}
+# ---- gradient-arena routing: the slice of a flat gradient arena that the gradient of a parameter is written into.  The record lives
+# ON the Parameter object (not in a table keyed by its address), so it dies with the parameter, an arena is freed as soon as its model
+# and TrainStep are, and a recycled device address can never alias a stale entry. ----
+_GRAD_ATTR = "_d2s_grad_slice"
 
 
 def register_grad_buffer(param, grad_view):
     """Route the gradient of `param` into `grad_view` (a slice of a flat gradient arena, see d2s.engine.ParamArena)."""
     base = grad_view._base if grad_view._base is not None else grad_view
-    _GRAD_BUFFERS[param.data_ptr()] = (base, grad_view.storage_offset(), grad_view.numel(), tuple(grad_view.shape))
+    setattr(param, _GRAD_ATTR, (base, grad_view.storage_offset(), grad_view.numel(), tuple(grad_view.shape)))
+
+
+def unregister_grad_buffer(param):
+    if hasattr(param, _GRAD_ATTR):
+        delattr(param, _GRAD_ATTR)
 
 
 def grad_buffer(param):
     """Tensor to write the gradient of `param` into: a FRESH view of its arena slice when registered (a fresh tensor
     object lets autograd's AccumulateGrad adopt it without a copy), otherwise a new tensor."""
-    ent = _GRAD_BUFFERS.get(param.data_ptr())
+    ent = getattr(param, _GRAD_ATTR, None)
     if ent is None:
         return torch.empty_like(param)
     base, off, numel, shape = ent
+    if shape != tuple(param.shape) or base.device != param.device:
+        raise lib.D2SError("parameter was reshaped / moved after its gradient arena was built (rebuild the TrainStep)")
     return base.view(-1)[off:off + numel].view(shape)
 
 
 GEMM_EXACT, GEMM_SPLIT, GEMM_BF16 = 0, 1, 2
 
+# Arithmetic mode of the GEMM / attention calls.  The C ABI takes it per call (no state in the library); this module keeps the
+# process default plus a per-thread override stack so that one module (e.g. the frozen teacher) can run in another mode than the
+# rest.  Autograd Functions record the mode of their forward and re-enter it in their backward (d2s.functional.mode_recorded),
+# because backward runs on autograd's own thread, outside any `with gemm_mode(...)` block of the caller.
+_default_mode = GEMM_EXACT
+_tls = threading.local()
+
 
 def set_gemm_mode(mode):
-    """0 exact fp32 MFMA (default, bit-for-bit an fp32 fma chain); 1 bf16x3 split on the bf16 matrix cores (fp32-class accuracy);
-    2 bf16 operands with fp32 accumulation (forward, dgrad and - in this mode only - wgrad GEMMs)."""
-    lib.load().d2s_set_gemm_mode(int(mode))
+    """Process default: 0 exact fp32 MFMA (bit-for-bit an fp32 fma chain); 1 bf16x3 split on the bf16 matrix cores (fp32-class
+    accuracy); 2 bf16 operands with fp32 accumulation (forward, dgrad and - in this mode only - wgrad GEMMs, bf16 attention)."""
+    global _default_mode
+    mode = int(mode)
+    if mode not in (GEMM_EXACT, GEMM_SPLIT, GEMM_BF16):
+        raise ValueError(f"gemm mode {mode}")
+    _default_mode = mode
 
 
 def get_gemm_mode():
-    return lib.load().d2s_get_gemm_mode()
+    stack = getattr(_tls, "stack", None)
+    return stack[-1] if stack else _default_mode
+
+
+class gemm_mode:
+    """with ops.gemm_mode(ops.GEMM_BF16): ...   - overrides the process default for the calls of this thread inside the block."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+        if self.mode not in (GEMM_EXACT, GEMM_SPLIT, GEMM_BF16):
+            raise ValueError(f"gemm mode {mode}")
+
+    def __enter__(self):
+        if not hasattr(_tls, "stack"):
+            _tls.stack = []
+        _tls.stack.append(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _tls.stack.pop()
+        return False

@@ -42,20 +42,20 @@ typedef struct ihipStream_t* d2s_stream_t; /* == hipStream_t */
  * exact fp32 column sum): 0 = exact fp32 MFMA; 1 = "bf16x3 split":
  * each fp32 operand is split into three bf16 pieces in registers and the 6 significant cross products run on the bf16 matrix
  * cores with fp32 accumulation (error ~2^-24 per product, fp32-class; 416 TFLOP/s effective peak); 2 = bf16 operands, fp32
- * accumulation (BASELINE config 5's bf16 regime).  Inputs and outputs stay fp32 in every mode. */
-void d2s_set_gemm_mode(int mode);
-int d2s_get_gemm_mode(void);
-size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K);
+ * accumulation (BASELINE config 5's bf16 regime).  Inputs and outputs stay fp32 in every mode.  `mode` is an argument of every
+ * call and of the matching workspace query (no process-global state: calls in different modes may run concurrently on different
+ * streams / threads, e.g. a bf16 teacher beside an fp32 student). */
+size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K, int mode);
 int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
                  int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, int aux_rows,
-                 int remap_rows_per_img, int remap_skip, int accumulate, void* workspace, size_t workspace_bytes,
+                 int remap_rows_per_img, int remap_skip, int accumulate, int mode, void* workspace, size_t workspace_bytes,
                  d2s_stream_t stream);
 /* nn.Linear parameter gradients in one pass over dy (autograd of F.linear at vit_models/dynamic_vit.py:169-175,218,231,491-531):
  * dW[n_out,n_in] (+)= dy[tokens,n_out]^T x[tokens,n_in];  db[n_out] (+)= column sums of dy (db may be NULL).  Exact fp32 MFMA,
  * deterministic split-K over the token rows; the bias gradient is folded out of the dy tiles the GEMM streams anyway. */
-size_t d2s_linear_wgrad_workspace_bytes(int tokens, int n_out, int n_in);
+size_t d2s_linear_wgrad_workspace_bytes(int tokens, int n_out, int n_in, int mode);
 int d2s_linear_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, float* db, int tokens,
-                         int n_out, int n_in, int accumulate, void* workspace, size_t workspace_bytes, d2s_stream_t stream);
+                         int n_out, int n_in, int accumulate, int mode, void* workspace, size_t workspace_bytes, d2s_stream_t stream);
 /* out[n] (+)= sum_m X[m][n]: bias gradients where no weight gradient is wanted. */
 size_t d2s_colsum_workspace_bytes(int M, int N);
 int d2s_colsum_f32(const float* X, long ldx, int M, int N, float* out, int accumulate, void* workspace,
@@ -169,8 +169,11 @@ int d2s_batchnorm_bwd(const float* x, const float* dy, const float* w, const flo
 
 /* ---- optimiser: torch.optim.AdamW (mask_predictor.py:229-230) over a flat arena, one launch ------------------------ */
 int d2s_adamw_chunk_elems(void);
+/* chunk_steps (n_chunks ints, device memory, zero-initialised by the caller): torch.optim.AdamW's per-parameter state['step'] - a
+ * tensor frozen during the warm-up epochs (utils.py:112-119) starts its bias correction at t = 1 when it is first updated; the call
+ * advances the counters of the active chunks.  NULL: `step` (>= 1) is used for every chunk. */
 int d2s_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const void* chunk_desc, int n_chunks,
-                   float beta1, float beta2, float eps, int step, float grad_scale, d2s_stream_t stream);
+                   float beta1, float beta2, float eps, int step, float grad_scale, int* chunk_steps, d2s_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -42,7 +42,32 @@ def _worker(rank, world, port, q):
     red.ready_from(5000)
     red.finish()
     ok = ok and torch.equal(arena.grads, torch.ones(10000) * sum(r + 1 for r in range(world)))
-    q.put((rank, bool(ok), spans))
+    # warm-up epoch (utils.py:112-119): only the predictor slices hold live gradients and no autograd hook fires (nothing upstream
+    # requires grad), so finish() must exchange exactly those slices and leave every frozen slice - stale values included - alone
+    total = sum(r + 1 for r in range(world))
+    red.set_live_ranges([(1000, 2000), (2000, 2500), (6000, 7000)])        # touching ranges merge
+    assert red.live == [(1000, 2500), (6000, 7000)] and red.live_elems() == 2500
+    arena.grads = torch.ones(10000) * (rank + 1)
+    reduced = []
+    orig_reduce = red._reduce
+    red._reduce = lambda lo, hi: (reduced.append((lo, hi)), orig_reduce(lo, hi))[1]
+    red.finish()
+    want = torch.ones(10000) * (rank + 1)
+    want[1000:2500] = total
+    want[6000:7000] = total
+    ok = ok and torch.equal(arena.grads, want) and reduced == [(6000, 7000), (1000, 2500)]
+    # first full epoch: the live set grows (cls_token / pos_embed style gaps stay out), hooks fire again, buckets count live elements only
+    red.set_live_ranges([(500, 9500)])
+    arena.grads = torch.ones(10000) * (rank + 1)
+    del reduced[:]
+    for lo in (9000, 7000, 5000, 2500, 100):
+        red.ready_from(lo)
+    red.finish()
+    want = torch.ones(10000) * (rank + 1)
+    want[500:9500] = total
+    ok = ok and torch.equal(arena.grads, want) and reduced[0] == (5000, 9500) and reduced[-1][0] == 500
+    ok = ok and all(reduced[i][0] == reduced[i + 1][1] for i in range(len(reduced) - 1))
+    q.put((rank, bool(ok), spans + reduced))
     dist.destroy_process_group()
 
 

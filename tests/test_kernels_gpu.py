@@ -294,7 +294,7 @@ def test_gemm_split_modes(ops, mode, rtol, atol):
     """mode 1 (bf16x3 split on the bf16 matrix cores) must meet the SAME tolerance as the exact fp32 kernel and be as close to
     an fp64 product as the CPU's fp32 GEMM is; mode 2 (plain bf16 operands) only the bf16 tolerance."""
     from d2s import lib
-    lib.load().d2s_set_gemm_mode(mode)
+    ops.set_gemm_mode(mode)
     try:
         for (M, N, K) in ((197 * 2, 1152, 384), (300, 96, 192), (128, 1000, 384), (391, 200, 36), (50, 1, 96), (1024, 1536, 384), (77, 192, 147)):
             x, w, b = _rand("mx", (M, K)), _rand("mw", (N, K), 0.05), _rand("mb", (N,), 0.1)
@@ -314,7 +314,7 @@ def test_gemm_split_modes(ops, mode, rtol, atol):
             got = ops.linear_fwd(x.to(_dev()), w.to(_dev()), b.to(_dev()), epi=ops.EPI_BIAS_RESID, aux=r.to(_dev())).cpu()
             np.testing.assert_allclose(got.numpy(), (ref32 + r).numpy(), rtol=rtol, atol=atol)
     finally:
-        lib.load().d2s_set_gemm_mode(0)
+        ops.set_gemm_mode(0)
 
 
 @pytest.mark.parametrize("tokens,n_out,n_in", [(197 * 8, 384, 1536), (1000, 96, 192), (130, 10, 24), (4100, 200, 72)])

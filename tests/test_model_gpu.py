@@ -190,6 +190,52 @@ def test_optimizer_steps_match_oracle(name, warmup):
             np.testing.assert_array_equal(got, sd_s[n], err_msg=n)
 
 
+def test_optimizer_warmup_to_full_transition():
+    """torch.optim.AdamW advances state['step'] per parameter, only when it has a gradient: backbone tensors frozen in the warm-up
+    epoch (utils.py:112-119) start their bias correction at t = 1 in the first full epoch.  Two steps in epoch 0 (warm-up: predictor
+    only), two in epoch 1 (everything), against the oracle's torch.optim.AdamW."""
+    from d2s.engine import TrainStep
+    dev = torch.device("cuda:0")
+    case = cases.MODEL_CASES["micro2"]
+    cfg = case["cfg"]
+    student, teacher, sd_s, sd_t = build_models(case, dev)
+    x, y = _t(cases.make_images(case)), _t(cases.make_labels(case))
+    hp = dict(lr=5e-4, min_lr=1e-5, weight_decay=0.05, epochs=25, warmup_steps=1)
+    ts = TrainStep(student, teacher, make_args(cfg), **hp)
+    st = O.TrainState({k: _t(v) for k, v in sd_s.items()}, {k: _t(v) for k, v in sd_t.items()}, cfg, **hp)
+    nsteps = 0
+    for epoch in (0, 1):
+        ts.set_epoch(epoch)
+        st.set_epoch(epoch)
+        for _ in range(2):
+            info = ts(x.to(dev), y.to(dev))
+            oinfo = st.step(x, y)
+            nsteps += 1
+            np.testing.assert_allclose(float(info["loss"]), float(oinfo["loss"]), rtol=5e-5, err_msg=f"epoch {epoch}")
+        if epoch == 0:
+            for n, p in student.named_parameters():
+                if "predictor" not in n:
+                    np.testing.assert_array_equal(p.detach().cpu().numpy(), sd_s[n], err_msg=n)
+    # per-tensor counters: predictor tensors were updated 4 times, backbone tensors twice
+    steps = ts.opt.chunk_steps.cpu().numpy()
+    for i, (n, p) in enumerate(zip(ts.arena.names, ts.arena.params_list)):
+        c0, c1 = ts.arena.chunk_range(i)
+        want = 0 if ("cls_token" in n or "pos_embed" in n) else (4 if "predictor" in n else 2)
+        assert (steps[c0:c1] == want).all(), (n, steps[c0:c1], want)
+    worst = 0.0
+    for n, p in student.named_parameters():
+        ref = st.sd_s[n].detach().numpy()
+        got = p.detach().cpu().numpy()
+        bad = ~np.isclose(got, ref, rtol=2e-4, atol=2e-6)
+        og = st.sd_s[n].grad
+        if not (og is not None and float(og.double().norm()) < 1e-6):
+            assert bad.mean() <= 2e-4, (n, float(bad.mean()))
+        # a wrong bias correction (global step 3 instead of per-tensor step 1) makes the first backbone update 0.1/ (1-0.9^3) ... i.e.
+        # several times too small or large: every element would miss by O(lr), which the rtol check above catches; this bounds the rest
+        worst = max(worst, float(np.abs(got - ref).max()))
+    assert worst <= 2 * nsteps * hp["lr"] * 1.01
+
+
 @pytest.mark.parametrize("tag", list(cases.PTK_CASES))
 def test_perturbed_topk_parity(tag):
     from d2s import synth

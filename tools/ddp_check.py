@@ -53,23 +53,34 @@ def main():
     B = per * world
     x = torch.from_numpy(synth.images(B, 3, case["cfg"]["img_size"], seed=77))
     y = torch.from_numpy(synth.labels(B, case["cfg"]["num_classes"], seed=77))
-    # tiny bucket so that several all-reduces are launched from inside backward (exercises the hook path)
+    # tiny bucket so that several all-reduces are launched from inside backward (exercises the hook path); warmup_steps=1: epoch 0
+    # trains the predictors only (live gradient set = their slices, exchanged by finish()), epoch 1 everything (hooks + buckets)
     s, t, args = build(case, dev)
-    ts = TrainStep(s, t, args, distributed=True, bucket_mb=0.25)
-    info = ts(x[rank * per:(rank + 1) * per].to(dev), y[rank * per:(rank + 1) * per].to(dev))
-    torch.cuda.synchronize()
-    grads = ts.arena.grads.clone() / world
-    params = ts.arena.params.clone()
-    ok = True
+    ts = TrainStep(s, t, args, distributed=True, bucket_mb=0.25, warmup_steps=1)
+    ref = None
     if rank == 0:
         s1, t1, args1 = build(case, dev)
-        ref = TrainStep(s1, t1, args1, distributed=False)
-        ref(x.to(dev), y.to(dev))
+        ref = TrainStep(s1, t1, args1, distributed=False, warmup_steps=1)
+    ok = True
+    for epoch in (0, 1):
+        ts.set_epoch(epoch)
+        live = list(ts.reducer.live)
+        if epoch == 0:
+            assert ts.reducer.live_elems() < ts.arena.total // 2, "warm-up epoch must only exchange the predictor slices"
+        info = ts(x[rank * per:(rank + 1) * per].to(dev), y[rank * per:(rank + 1) * per].to(dev))
         torch.cuda.synchronize()
-        gd = float((grads - ref.arena.grads).norm() / ref.arena.grads.norm())
-        pd = float((params - ref.arena.params).abs().max())
-        print(f"[ddp_check] world={world} backend={'nccl' if own_gpu else 'gloo'} rel grad diff {gd:.3e}  max param diff {pd:.3e}")
-        ok = gd < 1e-4 and pd < 2 * 5e-4 * 1.01
+        grads = ts.arena.grads.clone() / world
+        params = ts.arena.params.clone()
+        if rank == 0:
+            ref.set_epoch(epoch)
+            ref(x.to(dev), y.to(dev))
+            torch.cuda.synchronize()
+            sel = torch.cat([torch.arange(a, b) for a, b in live]).to(dev)       # the gradients the optimiser reads
+            gd = float((grads[sel] - ref.arena.grads[sel]).norm() / ref.arena.grads[sel].norm())
+            pd = float((params - ref.arena.params).abs().max())
+            print(f"[ddp_check] world={world} backend={'nccl' if own_gpu else 'gloo'} epoch {epoch} live {len(sel)}/{ts.arena.total} "
+                  f"rel grad diff {gd:.3e}  max param diff {pd:.3e}")
+            ok = ok and gd < 1e-4 and pd < 2 * 2 * 5e-4 * 1.01
     flag = torch.tensor([1 if ok else 0])
     dist.broadcast(flag.to(dev) if own_gpu else flag, src=0)
     dist.destroy_process_group()

@@ -9,7 +9,7 @@ from d2s import ops
 dev = torch.device("cuda:0")
 from d2s import lib
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0      # 0 exact f32 MFMA, 1 bf16x3 split (fp32-class), 2 bf16
-lib.load().d2s_set_gemm_mode(mode)
+ops.set_gemm_mode(mode)
 print("gemm mode", mode)
 B = int(os.environ.get("D2S_BENCH_B", "128"))
 shapes = []

@@ -8,7 +8,7 @@ import torch
 from d2s import ops, lib
 L = lib.load()
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-L.d2s_set_gemm_mode(mode)
+ops.set_gemm_mode(mode)
 dev = torch.device("cuda:0")
 for (M, N, K) in ((25216, 1536, 384), (25216, 384, 1536), (12672, 384, 384)):
     A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev); C = torch.empty(M, N, device=dev); b = torch.randn(N, device=dev)
