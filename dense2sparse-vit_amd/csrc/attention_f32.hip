@@ -103,42 +103,74 @@ __device__ __forceinline__ void mma_lds_reg_t(const f32x16& p, const float* __re
 // ---------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                       float* __restrict__ lse, float* __restrict__ cls_row, int n, int H,
-                                                       float scale) {
+// POLICY: Attention.softmax_with_policy (vit_models/dynamic_vit.py:195-214) fused into the same pass:
+//     mk_ij = policy[b,j] or (i == j);  e_ij = exp(S_ij - max_j S_ij) * mk_ij;  P_ij = (e_ij + eps/n) / (sum_j e_ij + eps)
+// The running maximum is taken over ALL keys (masked ones included, as the reference does), masked keys add nothing to l or O, and the
+// eps terms enter once at the end: O_i = (sum_j e_ij v_j + (eps/n) sum_j v_j) / (l_i + eps).  Saved for the backward: lse_i = m_i +
+// log(l_i + eps) (so that e_ij / (l_i + eps) = exp(S_ij - lse_i) mk_ij) and cinv_i = (eps/n) / (l_i + eps).
+// VARLEN: ragged packed batch (inference with a dynamic keep ratio, :935-949): image b owns rows cu[b] .. cu[b+1] of qkv / out, its
+// lse / CLS row live at [h * total + cu[b] + i].
+struct AttnFwdArgs {
+    const float* qkv; float* out; float* lse; float* cls_row;
+    const float* policy; float* cinv; const int* cu;
+    int n, H; float scale, eps; int total;
+};
+
+template <bool POLICY, bool VARLEN>
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[32 * PITCH];
     __shared__ __attribute__((aligned(16))) float Vs[32 * PITCH];
+    __shared__ float pol_s[32];
+    __shared__ __attribute__((aligned(16))) float vred[POLICY ? 16 * 64 : 4];
+    __shared__ float vsum_s[64];
     extern __shared__ __attribute__((aligned(16))) float cls_s[];  // [n] raw scaled scores of query 0 (block 0 only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int H = a.H;
     const int b = blockIdx.y / H, h = blockIdx.y % H;
     const long ld = 3L * H * DH;
-    const float* qb = qkv + (long)b * n * ld + h * DH;
+    const int row_base = VARLEN ? a.cu[b] : 0;
+    const int n = VARLEN ? a.cu[b + 1] - row_base : a.n;
+    if (VARLEN && (int)blockIdx.x * 128 >= n) return;                // block-uniform: this image has no queries in this tile
+    const long tok0 = VARLEN ? (long)row_base : (long)b * n;       // first token row of the image
+    const float* qb = a.qkv + tok0 * ld + h * DH;
     const float* kb = qb + (long)H * DH;
     const float* vb = kb + (long)H * DH;
+    const float* polb = POLICY ? a.policy + (long)b * n : nullptr;
+    const float scale = a.scale;
     const int q0 = blockIdx.x * 128 + wave * 32;
     const bool active = q0 < n;
-    const bool want_cls = cls_row != nullptr && blockIdx.x == 0 && wave == 0;
+    const bool want_cls = a.cls_row != nullptr && blockIdx.x == 0 && wave == 0;
+    const int qi = q0 + l31;
 
     f32x4 qreg[8];
-    load_rows_regs(qb, ld, q0 + l31, n, half, scale, qreg);
+    load_rows_regs(qb, ld, qi, n, half, scale, qreg);
 
     f32x16 o[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
+    f32x4 vacc = {0.f, 0.f, 0.f, 0.f};
 
     const int ntiles = (n + 31) / 32;
     f32x4 kr[2], vr[2];
+    float pr = 0.f;
     tile_load(kb, ld, 0, n, tid, kr);
     tile_load(vb, ld, 0, n, tid, vr);
+    if (POLICY && tid < 32) pr = tid < n ? polb[tid] : 0.f;
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
         tile_store(Ks, tid, kr);
         tile_store(Vs, tid, vr);
+        if (POLICY) {
+            if (tid < 32) pol_s[tid] = pr;
+            vacc += vr[0];      // column sums of V over every key (rows beyond n were loaded as zeros)
+            vacc += vr[1];
+        }
         __syncthreads();
         if (t + 1 < ntiles) {
             tile_load(kb, ld, (t + 1) * 32, n, tid, kr);
             tile_load(vb, ld, (t + 1) * 32, n, tid, vr);
+            if (POLICY && tid < 32) { const int kj = (t + 1) * 32 + tid; pr = kj < n ? polb[kj] : 0.f; }
         }
         if (!active) continue;
         f32x16 s;
@@ -166,6 +198,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             s[r] = __expf(s[r] - m_new);
+            if (POLICY) {
+                const int kr_ = mfma32_row(r, half);
+                s[r] *= (kv0 + kr_ == qi) ? 1.f : pol_s[kr_];
+            }
             rs += s[r];
         }
         rs += __shfl_xor(rs, 32, 64);
@@ -179,26 +215,50 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const float* __restric
         }
         mma_lds_reg_t(s, Vs, l31, half, o, min(4, (n - kv0 + 7) >> 3));
     }
+    const float c = POLICY ? a.eps / (float)n : 0.f;
+    if (POLICY) {   // fold the 16 per-thread partial column sums of every column quad (threads with equal tid & 15) -> vsum_s[64]
+        *reinterpret_cast<f32x4*>(&vred[(tid >> 4) * 64 + (tid & 15) * 4]) = vacc;
+        __syncthreads();
+        if (tid < 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t += vred[g * 64 + tid];
+            vsum_s[tid] = t * c;
+        }
+        __syncthreads();
+    }
     if (!active) return;
-    const float inv_l = 1.0f / l_run;
-    if (q0 + l31 < n) {      // registers 4g .. 4g+3 of o[dt] hold d = 32 dt + 8 g + 4 half + 0..3 of this lane's query
-        float* p = out + ((long)b * n + q0 + l31) * H * DH + h * DH;
+    const float inv_l = 1.0f / (POLICY ? l_run + a.eps : l_run);
+    if (qi < n) {      // registers 4g .. 4g+3 of o[dt] hold d = 32 dt + 8 g + 4 half + 0..3 of this lane's query
+        float* p = a.out + (tok0 + qi) * H * DH + h * DH;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = o[dt][4 * g + j] * inv_l;
+                for (int j = 0; j < 4; ++j) {
+                    float num = o[dt][4 * g + j];
+                    if (POLICY) num += vsum_s[32 * dt + 8 * g + 4 * half + j];
+                    v[j] = num * inv_l;
+                }
                 *reinterpret_cast<f32x4*>(p + 32 * dt + 8 * g + 4 * half) = v;
             }
     }
-    if (half == 0 && q0 + l31 < n) lse[((long)b * H + h) * n + q0 + l31] = m_run + logf(l_run);
+    const long stat0 = VARLEN ? (long)h * a.total + row_base : ((long)b * H + h) * n;
+    if (half == 0 && qi < n) {
+        if (a.lse) a.lse[stat0 + qi] = m_run + logf(POLICY ? l_run + a.eps : l_run);
+        if (POLICY && a.cinv) a.cinv[stat0 + qi] = c * inv_l;
+    }
     if (want_cls) {
         const float m0 = __shfl(m_run, 0, 64), il0 = __shfl(inv_l, 0, 64);
-        float* cr = cls_row + ((long)b * H + h) * n;
+        float* cr = a.cls_row + stat0;
         // cls_s was written by lanes 0 and 32 of this wave only; same-wave LDS accesses are ordered
-        for (int j = lane; j < n; j += 64) cr[j] = expf(cls_s[j] - m0) * il0;
+        for (int j = lane; j < n; j += 64) {
+            float e = expf(cls_s[j] - m0);
+            if (POLICY) e = e * (j == 0 ? 1.f : polb[j]) + c;
+            cr[j] = e * il0;
+        }
     }
 }
 
@@ -219,11 +279,17 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 // ---------------------------------------------------------------------------------------------------------
 // backward, dQ: one wave per 32 queries, loops over key tiles (same orientation as forward)
 // ---------------------------------------------------------------------------------------------------------
+// POLICY: dS_ij = exp(S_ij - lse_i) mk_ij (dP_ij - delta_i) with lse_i = m_i + log(l_i + eps); the eps/n term of P does not depend on
+// S.  (The O(eps) gradient through the row maximum, which the reference's autograd carries because it does not detach the max, is
+// left out: it is <= eps = 1e-6 relative.)
+template <bool POLICY>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          float* __restrict__ dqkv, int n, int H, float scale) {
+                                                          float* __restrict__ dqkv, int n, int H, float scale,
+                                                          const float* __restrict__ policy) {
     __shared__ __attribute__((aligned(16))) float Ks[32 * PITCH];
     __shared__ __attribute__((aligned(16))) float Vs[32 * PITCH];
+    __shared__ float pol_s[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y / H, h = blockIdx.y % H;
     const long ld = 3L * H * DH, ldo = (long)H * DH;
@@ -247,16 +313,21 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const float* __rest
 
     const int ntiles = (n + 31) / 32;
     f32x4 kr[2], vr[2];
+    float pr = 0.f;
+    const float* polb = POLICY ? policy + (long)b * n : nullptr;
     tile_load(kb, ld, 0, n, tid, kr);
     tile_load(vb, ld, 0, n, tid, vr);
+    if (POLICY && tid < 32) pr = tid < n ? polb[tid] : 0.f;
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
         tile_store(Ks, tid, kr);
         tile_store(Vs, tid, vr);
+        if (POLICY && tid < 32) pol_s[tid] = pr;
         __syncthreads();
         if (t + 1 < ntiles) {
             tile_load(kb, ld, (t + 1) * 32, n, tid, kr);
             tile_load(vb, ld, (t + 1) * 32, n, tid, vr);
+            if (POLICY && tid < 32) { const int kj = (t + 1) * 32 + tid; pr = kj < n ? polb[kj] : 0.f; }
         }
         if (!active) continue;
         f32x16 s, dp;
@@ -267,7 +338,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const float* __rest
         const int kv0 = t * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = (kv0 + mfma32_row(r, half) < n) ? __expf(s[r] - lse_i) : 0.f;
+            const int kr_ = mfma32_row(r, half);
+            float p = (kv0 + kr_ < n) ? __expf(s[r] - lse_i) : 0.f;
+            if (POLICY) p *= (kv0 + kr_ == q0 + l31) ? 1.f : pol_s[kr_];
             s[r] = p * (dp[r] - dl_i);          // dS^T
         }
         mma_reg_lds(s, Ks, l31, half, dq, min(4, (n - kv0 + 7) >> 3));      // dQ[query][d] += sum_key dS^T[key][query] K[key][d]
@@ -288,12 +361,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------------------
 // backward, dK / dV: one wave per 32 keys, loops over query tiles (natural orientation S = Q K^T)
 // ---------------------------------------------------------------------------------------------------------
+// POLICY: P_ij = exp(S_ij - lse_i) mk_ij + cinv_i feeds dV (the eps/n term reaches every key, masked or not); dS as in the dQ kernel.
+template <bool POLICY>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           float* __restrict__ dqkv, int n, int H, float scale) {
+                                                           float* __restrict__ dqkv, int n, int H, float scale,
+                                                           const float* __restrict__ policy, const float* __restrict__ cinv) {
     __shared__ __attribute__((aligned(16))) float Qs[32 * PITCH];
     __shared__ __attribute__((aligned(16))) float Ds[32 * PITCH];
-    __shared__ float lse_s[32], dl_s[32];
+    __shared__ float lse_s[32], dl_s[32], ci_s[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y / H, h = blockIdx.y % H;
     const long ld = 3L * H * DH, ldo = (long)H * DH;
@@ -316,15 +392,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
 
     const int ntiles = (n + 31) / 32;
     f32x4 qr[2], dr[2];
-    float lr = 0.f, dlr = 0.f;
+    float lr = 0.f, dlr = 0.f, cir = 0.f;
+    const float* ci_b = POLICY ? cinv + ((long)b * H + h) * n : nullptr;
+    const float pol_key = (POLICY && k0 + l31 < n) ? policy[(long)b * n + k0 + l31] : 0.f;   // this lane's key
     tile_load(qb, ld, 0, n, tid, qr);
     tile_load(dob, ldo, 0, n, tid, dr);
-    if (tid < 32) { lr = tid < n ? lse_b[tid] : INFINITY; dlr = tid < n ? dl_b[tid] : 0.f; }
+    if (tid < 32) { lr = tid < n ? lse_b[tid] : INFINITY; dlr = tid < n ? dl_b[tid] : 0.f; if (POLICY) cir = tid < n ? ci_b[tid] : 0.f; }
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
         tile_store(Qs, tid, qr);
         tile_store(Ds, tid, dr);
-        if (tid < 32) { lse_s[tid] = lr; dl_s[tid] = dlr; }
+        if (tid < 32) { lse_s[tid] = lr; dl_s[tid] = dlr; if (POLICY) ci_s[tid] = cir; }
         __syncthreads();
         if (t + 1 < ntiles) {
             tile_load(qb, ld, (t + 1) * 32, n, tid, qr);
@@ -333,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
                 const int qi = (t + 1) * 32 + tid;
                 lr = qi < n ? lse_b[qi] : INFINITY;
                 dlr = qi < n ? dl_b[qi] : 0.f;
+                if (POLICY) cir = qi < n ? ci_b[qi] : 0.f;
             }
         }
         if (!active) continue;
@@ -344,8 +423,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qi = mfma32_row(r, half);
-            const float p = __expf(s[r] - lse_s[qi]);  // rows beyond n carry lse = +inf -> p = 0
-            s[r] = p;
+            float p = __expf(s[r] - lse_s[qi]);  // rows beyond n carry lse = +inf -> p = 0
+            if (POLICY) p *= (t * 32 + qi == k0 + l31) ? 1.f : pol_key;
+            s[r] = POLICY ? p + ci_s[qi] : p;
             dp[r] = p * (dp[r] - dl_s[qi]);
         }
         const int qgroups = min(4, (n - t * 32 + 7) >> 3);          // query rows of this tile that exist
@@ -378,8 +458,32 @@ int d2s_attn_fwd_f32(const float* qkv, float* out, float* lse, float* cls_row, i
                      hipStream_t stream) {
     if (!qkv || !out || !lse || B <= 0 || n <= 0 || H <= 0 || n > 8192) return D2S_ERR_ARG;
     dim3 grid((n + 127) / 128, B * H), block(256);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, block, cls_row ? (size_t)n * sizeof(float) : 0, stream, qkv, out, lse, cls_row, n, H,
-                       scale);
+    AttnFwdArgs a{qkv, out, lse, cls_row, nullptr, nullptr, nullptr, n, H, scale, 0.f, 0};
+    hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, block, cls_row ? (size_t)n * sizeof(float) : 0, stream, a);
+    return d2s_check_launch();
+}
+
+// Attention with the keep policy of the dynamic-keep-ratio training path fused in (vit_models/dynamic_vit.py:195-214,216-236 with
+// policy != None): policy [B,n] (1 = kept; entry 0 is the CLS token).  lse [B,H,n] = m + log(l + eps), cinv [B,H,n] = (eps/n)/(l + eps)
+// are what the backward needs.
+int d2s_attn_policy_fwd_f32(const float* qkv, const float* policy, float* out, float* lse, float* cinv, float* cls_row, int B, int n,
+                            int H, float scale, float eps, hipStream_t stream) {
+    if (!qkv || !policy || !out || !lse || !cinv || B <= 0 || n <= 0 || H <= 0 || n > 8192) return D2S_ERR_ARG;
+    dim3 grid((n + 127) / 128, B * H), block(256);
+    AttnFwdArgs a{qkv, out, lse, cls_row, policy, cinv, nullptr, n, H, scale, eps, 0};
+    hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, block, cls_row ? (size_t)n * sizeof(float) : 0, stream, a);
+    return d2s_check_launch();
+}
+
+// Ragged packed batch (inference with a dynamic keep ratio, vit_models/dynamic_vit.py:935-949): qkv [total,3,H,64], image b = rows
+// cu_seqlens[b] .. cu_seqlens[b+1]; out [total,H*64]; cls_row (optional) [H,total]: softmax row of each image's first (CLS) token.
+// max_n bounds the longest image (sizes the grid; any upper bound works).  Forward only.
+int d2s_attn_varlen_fwd_f32(const float* qkv, const int* cu_seqlens, float* out, float* cls_row, int B, int total, int max_n, int H,
+                            float scale, hipStream_t stream) {
+    if (!qkv || !cu_seqlens || !out || B <= 0 || total <= 0 || max_n <= 0 || max_n > 8192 || H <= 0) return D2S_ERR_ARG;
+    dim3 grid((max_n + 127) / 128, B * H), block(256);
+    AttnFwdArgs a{qkv, out, nullptr, cls_row, nullptr, nullptr, cu_seqlens, 0, H, scale, 0.f, total};
+    hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, block, cls_row ? (size_t)max_n * sizeof(float) : 0, stream, a);
     return d2s_check_launch();
 }
 
@@ -398,8 +502,22 @@ int d2s_attn_bwd_f32(const float* qkv, const float* out, const float* dout, cons
     const long rows = (long)B * n;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, out, dout, delta_ws, rows, n, H);
     dim3 grid((n + 127) / 128, B * H), block(256);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, n, H, scale);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, n, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, n, H, scale,
+                       static_cast<const float*>(nullptr));
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, n, H, scale,
+                       static_cast<const float*>(nullptr), static_cast<const float*>(nullptr));
+    return d2s_check_launch();
+}
+
+// Backward of d2s_attn_policy_fwd_f32 (lse, cinv as that call wrote them).
+int d2s_attn_policy_bwd_f32(const float* qkv, const float* policy, const float* out, const float* dout, const float* lse,
+                            const float* cinv, float* dqkv, float* delta_ws, int B, int n, int H, float scale, hipStream_t stream) {
+    if (!qkv || !policy || !out || !dout || !lse || !cinv || !dqkv || !delta_ws || B <= 0 || n <= 0 || H <= 0) return D2S_ERR_ARG;
+    const long rows = (long)B * n;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, out, dout, delta_ws, rows, n, H);
+    dim3 grid((n + 127) / 128, B * H), block(256);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, n, H, scale, policy);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, n, H, scale, policy, cinv);
     return d2s_check_launch();
 }
 

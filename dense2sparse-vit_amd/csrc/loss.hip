@@ -66,7 +66,7 @@ template <int NE>
 __global__ __launch_bounds__(256) void kl_rows_kernel(const float* __restrict__ s, RowMap sm, const float* __restrict__ t, RowMap tm,
                                                       const long long* __restrict__ t_ids, const long long* __restrict__ labels,
                                                       float* __restrict__ loss_row, float* __restrict__ grad, long rows, int C,
-                                                      int mode) {
+                                                      int mode, const float* __restrict__ row_weight) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -165,6 +165,17 @@ __global__ __launch_bounds__(256) void kl_rows_kernel(const float* __restrict__ 
         }
     }
     loss = wave_sum(loss);
+    if (row_weight) {       // weighted rows (dynamic keep ratio: mask / count restricts the mean to the kept tokens)
+        const float w = row_weight[row];
+        loss *= w;
+        if (gr) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const int c = lane + i * 64;
+                if (c < C) gr[c] *= w;      // same lane wrote gr[c] above
+            }
+        }
+    }
     if (lane == 0) loss_row[row] = loss;
 }
 
@@ -284,13 +295,13 @@ int d2s_gather_renorm(const float* in, const long long* ids, float* out, int B, 
 // loss_row [rows]; grad [rows, C] contiguous (may be null).  C <= 1024.
 int d2s_kl_rows(const float* s, long s_rpg, long s_gs, long s_rs, long s_off, const float* t, long t_rpg, long t_gs, long t_rs,
                 long t_off, const long long* t_ids, const long long* labels, float* loss_row, float* grad, long rows, int C,
-                int mode, hipStream_t stream) {
+                int mode, const float* row_weight, hipStream_t stream) {
     if (!s || !loss_row || rows <= 0 || C <= 0 || C > 1024 || mode < 0 || mode > 4) return D2S_ERR_ARG;
     if (mode == 2 ? !labels : !t) return D2S_ERR_ARG;
     RowMap sm{s_rpg, s_gs, s_rs, s_off}, tm{t_rpg > 0 ? t_rpg : 1, t_gs, t_rs, t_off};
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     const int ne = (C + 63) / 64;
-#define D2S_KL(NE) hipLaunchKernelGGL(kl_rows_kernel<NE>, grid, block, 0, stream, s, sm, t, tm, t_ids, labels, loss_row, grad, rows, C, mode)
+#define D2S_KL(NE) hipLaunchKernelGGL(kl_rows_kernel<NE>, grid, block, 0, stream, s, sm, t, tm, t_ids, labels, loss_row, grad, rows, C, mode, row_weight)
     if (ne <= 1) D2S_KL(1);
     else if (ne <= 2) D2S_KL(2);
     else if (ne <= 4) D2S_KL(4);

@@ -123,7 +123,9 @@ class BlockFn(torch.autograd.Function):
     """One pre-norm transformer block on a packed [B, n, D] token tensor; also returns the CLS row of the softmax."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, heads, eps, want_cls, scale):
+    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, heads, eps, want_cls, scale, *extra):
+        policy = extra[0] if extra else None         # optional 18th input: keep policy [B, n] of the dynamic-keep-ratio path
+        ctx.nextra = len(extra)
         B, n, D = x.shape
         M = B * n
         x = x.contiguous()
@@ -135,7 +137,10 @@ class BlockFn(torch.autograd.Function):
             ln1, _, _ = ops.layernorm_fwd(x, cmap, n1w, n1b, M, D, eps, stats=False)
             qkv = ops.linear_fwd(ln1, qkvw, qkvb)
             del ln1
-            ao, _, cls_row = ops.attn_fwd(qkv, B, n, heads, scale, want_cls)
+            if policy is None:
+                ao, _, cls_row = ops.attn_fwd(qkv, B, n, heads, scale, want_cls)
+            else:
+                ao, _, _, cls_row = ops.attn_policy_fwd(qkv, policy, B, n, heads, scale, want_cls=want_cls)
             del qkv
             x1 = ops.linear_fwd(ao, projw, projb, epi=ops.EPI_BIAS_RESID, aux=x.view(M, D))
             ln2, _, _ = ops.layernorm_fwd(x1, cmap, n2w, n2b, M, D, eps, stats=False)
@@ -146,7 +151,11 @@ class BlockFn(torch.autograd.Function):
             return y.view(B, n, D), cls_row
         ln1, mean1, rstd1 = ops.layernorm_fwd(x, cmap, n1w, n1b, M, D, eps)
         qkv = ops.linear_fwd(ln1, qkvw, qkvb)
-        ao, lse, cls_row = ops.attn_fwd(qkv, B, n, heads, scale, want_cls)
+        cinv = None
+        if policy is None:
+            ao, lse, cls_row = ops.attn_fwd(qkv, B, n, heads, scale, want_cls)
+        else:   # dynamic keep ratio: softmax_with_policy fused into the attention pass (:195-214)
+            ao, lse, cinv, cls_row = ops.attn_policy_fwd(qkv, policy, B, n, heads, scale, want_cls=want_cls)
         x2d = x.view(M, D)
         x1 = ops.linear_fwd(ao, projw, projb, epi=ops.EPI_BIAS_RESID, aux=x2d)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x1, cmap, n2w, n2b, M, D, eps)
@@ -155,6 +164,7 @@ class BlockFn(torch.autograd.Function):
         y = ops.linear_fwd(h, fc2w, fc2b, epi=ops.EPI_BIAS_RESID, aux=x1)
         ctx.save_for_backward(x, n1w, qkvw, projw, n2w, fc1w, fc2w, mean1, rstd1, ln1, qkv, ao, lse, x1, mean2, rstd2, ln2, z, h,
                               n1b, qkvb, projb, n2b, fc1b, fc2b)
+        ctx.policy = (policy, cinv)
         ctx.dims = (B, n, D, heads, scale)
         if cls_row is None:
             cls_row = torch.empty((0,), device=x.device)
@@ -189,7 +199,11 @@ class BlockFn(torch.autograd.Function):
         # ---- attention branch ----
         grads[5], grads[6] = ops.linear_param_grads(g1, ao, projw, projb, wants[5], wants[6])
         dao = ops.linear_dgrad(g1, projw)
-        dqkv = ops.attn_bwd(qkv, ao, dao, lse, B, n, heads, scale)
+        policy, cinv = ctx.policy
+        if policy is None:
+            dqkv = ops.attn_bwd(qkv, ao, dao, lse, B, n, heads, scale)
+        else:
+            dqkv = ops.attn_policy_bwd(qkv, policy, ao, dao, lse, cinv, B, n, heads, scale)
         grads[3], grads[4] = ops.linear_param_grads(dqkv, ln1, qkvw, qkvb, wants[3], wants[4])
         gx = None
         if wants[0] or wants[1] or wants[2]:
@@ -201,7 +215,7 @@ class BlockFn(torch.autograd.Function):
             grads[1], grads[2] = (dn1w if wants[1] else None), (dn1b if wants[2] else None)
             gx = gx.view(B, n, D) if wants[0] else None
         grads[0] = gx
-        return tuple(grads) + (None, None, None, None)
+        return tuple(grads) + (None, None, None, None) + (None,) * ctx.nextra
 
 
 @mode_recorded
@@ -342,6 +356,30 @@ class HeadFn(torch.autograd.Function):
                 dhw, dhb, None)
 
 
+def as_policy(policy, B, n):
+    """[B,n,1] / [B,n] keep policy of the reference (:892-894) -> contiguous fp32 [B,n] (no copy when it already is)."""
+    p = policy.reshape(B, n)
+    if p.dtype != torch.float32:
+        p = p.float()
+    return p.contiguous()
+
+
+def ragged_block_forward(xp, cu, B, max_n, params, heads, eps, scale, want_cls=False):
+    """One transformer block on a ragged packed batch [total, D] (inference with a dynamic keep ratio, :935-949: every image keeps its
+    own number of tokens).  LayerNorm and the four GEMMs run over all packed rows at once, attention per image through cu_seqlens.
+    Forward only.  Returns (y [total, D], cls_rows [H, total] or None)."""
+    n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = params
+    total, D = xp.shape
+    cmap = ops.contiguous_map(total, D)
+    ln1, _, _ = ops.layernorm_fwd(xp, cmap, n1w, n1b, total, D, eps, stats=False)
+    qkv = ops.linear_fwd(ln1, qkvw, qkvb)
+    ao, cls_rows = ops.attn_varlen_fwd(qkv, cu, B, total, max_n, heads, scale, want_cls=want_cls)
+    x1 = ops.linear_fwd(ao, projw, projb, epi=ops.EPI_BIAS_RESID, aux=xp)
+    ln2, _, _ = ops.layernorm_fwd(x1, cmap, n2w, n2b, total, D, eps, stats=False)
+    h = ops.linear_fwd(ln2, fc1w, fc1b, epi=ops.EPI_BIAS_GELU)
+    return ops.linear_fwd(h, fc2w, fc2b, epi=ops.EPI_BIAS_RESID, aux=x1), cls_rows
+
+
 def rows_map_3d(t):
     """Row map (relative to t.data_ptr()) of a [B, R, C] tensor whose last dim is dense."""
     assert t.dim() == 3 and t.stride(2) == 1
@@ -354,7 +392,9 @@ class RowLossFn(torch.autograd.Function):
     outputs).  `s` is [rows, C] contiguous or a [B, R, C] view with a dense last dim."""
 
     @staticmethod
-    def forward(ctx, s, mode, t, t_ids, labels, denom):
+    def forward(ctx, s, mode, t, t_ids, labels, denom, *extra):
+        row_weight = extra[0] if extra else None      # optional 7th input: per-row weights [rows]
+        ctx.nextra = len(extra)
         if s.dim() == 3:
             smap = rows_map_3d(s)
             rows, C = s.shape[0] * s.shape[1], s.shape[2]
@@ -374,7 +414,8 @@ class RowLossFn(torch.autograd.Function):
             else:
                 t = t.contiguous()
                 tmap = ops.contiguous_map(rows, C)
-        loss_row, grad = ops.kl_rows(s, smap, rows, C, mode, t=t, t_map=tmap, t_ids=tid, labels=labels, want_grad=True)
+        loss_row, grad = ops.kl_rows(s, smap, rows, C, mode, t=t, t_map=tmap, t_ids=tid, labels=labels, want_grad=True,
+                                     row_weight=row_weight)
         ctx.save_for_backward(grad)
         ctx.meta = (tuple(s.shape), float(denom))
         return ops.sum_scalar(loss_row, 1.0 / float(denom))
@@ -384,7 +425,7 @@ class RowLossFn(torch.autograd.Function):
         (grad,) = ctx.saved_tensors
         shape, denom = ctx.meta
         gs = ops.scale_by_scalar(grad, g.contiguous(), 1.0 / denom)
-        return gs.view(shape), None, None, None, None, None
+        return (gs.view(shape), None, None, None, None, None) + (None,) * ctx.nextra
 
 
 class AddClsPosFn(torch.autograd.Function):
@@ -481,13 +522,20 @@ class LinearFn(torch.autograd.Function):
 
 @mode_recorded
 class AttnCoreFn(torch.autograd.Function):
-    """softmax(q k^T / sqrt(dh)) v on the raw qkv Linear output [B*n, 3*H*64] (+ CLS softmax row)."""
+    """softmax(q k^T / sqrt(dh)) v on the raw qkv Linear output [B*n, 3*H*64] (+ CLS softmax row); with a 7th input `policy` [B, n]
+    the softmax is Attention.softmax_with_policy (:195-214), fused."""
 
     @staticmethod
-    def forward(ctx, qkv, B, n, H, scale, want_cls):
+    def forward(ctx, qkv, B, n, H, scale, want_cls, *extra):
         qkv = qkv.contiguous()
-        out, lse, cls_row = ops.attn_fwd(qkv, B, n, H, scale, want_cls)
-        ctx.save_for_backward(qkv, out, lse)
+        policy = extra[0] if extra else None
+        ctx.nextra = len(extra)
+        if policy is None:
+            out, lse, cls_row = ops.attn_fwd(qkv, B, n, H, scale, want_cls)
+            ctx.save_for_backward(qkv, out, lse)
+        else:
+            out, lse, cinv, cls_row = ops.attn_policy_fwd(qkv, policy, B, n, H, scale, want_cls=want_cls)
+            ctx.save_for_backward(qkv, out, lse, cinv, policy)
         ctx.dims = (B, n, H, scale)
         if cls_row is None:
             cls_row = torch.empty((0,), device=qkv.device)
@@ -496,9 +544,14 @@ class AttnCoreFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _gc):
-        qkv, out, lse = ctx.saved_tensors
         B, n, H, scale = ctx.dims
-        return ops.attn_bwd(qkv, out, g.contiguous(), lse, B, n, H, scale), None, None, None, None, None
+        if len(ctx.saved_tensors) == 3:
+            qkv, out, lse = ctx.saved_tensors
+            dqkv = ops.attn_bwd(qkv, out, g.contiguous(), lse, B, n, H, scale)
+        else:
+            qkv, out, lse, cinv, policy = ctx.saved_tensors
+            dqkv = ops.attn_policy_bwd(qkv, policy, out, g.contiguous(), lse, cinv, B, n, H, scale)
+        return (dqkv, None, None, None, None, None) + (None,) * ctx.nextra
 
 
 class PerturbedTopKFn(torch.autograd.Function):

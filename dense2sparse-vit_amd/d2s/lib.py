@@ -52,7 +52,18 @@ _SIGS = {
     "d2s_attn_delta": (I, [P, P, P, I, I, I]),
     "d2s_teacher_target": (I, [P, P, I, I, I, I]),
     "d2s_gather_renorm": (I, [P, P, P, I, I, I, I]),
-    "d2s_kl_rows": (I, [P, L, L, L, L, P, L, L, L, L, P, P, P, P, L, I, I]),
+    "d2s_kl_rows": (I, [P, L, L, L, L, P, L, L, L, L, P, P, P, P, L, I, I, P]),
+    "d2s_select_threshold": (I, [P, I, I, F, P, L, I, P]),
+    "d2s_gather_rows_i32": (I, [P, P, P, I, I]),
+    "d2s_ragged_offsets": (I, [P, I, I, P]),
+    "d2s_ragged_pack": (I, [P, P, P, P, P, I, I, I]),
+    "d2s_mask_row_weights": (I, [P, L, P]),
+    "d2s_dense_mask_agreement": (I, [P, P, I, I, P]),
+    "d2s_patch_keep_mask": (I, [P, I, I, I, P]),
+    "d2s_compose_ids": (I, [P, I, P, I, P, I]),
+    "d2s_attn_policy_fwd_f32": (I, [P, P, P, P, P, P, I, I, I, F, F]),
+    "d2s_attn_policy_bwd_f32": (I, [P, P, P, P, P, P, P, P, I, I, I, F]),
+    "d2s_attn_varlen_fwd_f32": (I, [P, P, P, P, I, I, I, I, F]),
     "d2s_sum_scalar": (I, [P, L, F, P]),
     "d2s_scale_by_scalar": (I, [P, P, F, P, L]),
     "d2s_mask_agreement": (I, [P, P, I, I, I, P]),

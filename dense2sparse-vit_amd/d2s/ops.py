@@ -292,12 +292,104 @@ def gather_renorm(target, ids, normalize=True):
     return out
 
 
-def kl_rows(s, s_map, rows, C, mode, t=None, t_map=(1, 0, 0, 0), t_ids=None, labels=None, want_grad=True):
+def kl_rows(s, s_map, rows, C, mode, t=None, t_map=(1, 0, 0, 0), t_ids=None, labels=None, want_grad=True, row_weight=None):
+    """row_weight [rows]: every row's loss and gradient are scaled by it (mask / count restricts a mean to the kept tokens)."""
     loss_row = torch.empty((rows,), dtype=torch.float32, device=s.device)
     grad = torch.empty((rows, C), dtype=torch.float32, device=s.device) if want_grad else None
     lib.call("d2s_kl_rows", lib.ptr(s), *s_map, lib.ptr(t), *t_map, lib.ptr(t_ids), lib.ptr(labels), lib.ptr(loss_row),
-             lib.ptr(grad), rows, C, mode)
+             lib.ptr(grad), rows, C, mode, lib.ptr(row_weight))
     return loss_row, grad
+
+
+# ---- dynamic keep ratio (--patch-score-threshold): vit_models/dynamic_vit.py:880-894, :935-949 ----
+def select_threshold(probs, threshold, lead=0):
+    """-> (mask [B, lead + T] float 0/1, counts [B] int32): keep the tokens whose ascending cumulative probability exceeds `threshold`;
+    the `lead` first columns are 1 (lead=1: the attention policy row [CLS, tokens])."""
+    _f32(probs)
+    B, T = probs.shape
+    mask = torch.empty((B, lead + T), dtype=torch.float32, device=probs.device)
+    counts = torch.empty((B,), dtype=torch.int32, device=probs.device)
+    lib.call("d2s_select_threshold", lib.ptr(probs), B, T, float(threshold), lib.ptr(mask), lead + T, int(lead), lib.ptr(counts))
+    return mask, counts
+
+
+def gather_rows_i32(src, idx, rows):
+    D = src.shape[-1]
+    dst = torch.empty((rows, D), dtype=torch.float32, device=src.device)
+    lib.call("d2s_gather_rows_i32", lib.ptr(_f32(src)), lib.ptr(idx), lib.ptr(dst), rows, D)
+    return dst
+
+
+def ragged_offsets(counts, extra=1):
+    cu = torch.empty((counts.numel() + 1,), dtype=torch.int32, device=counts.device)
+    lib.call("d2s_ragged_offsets", lib.ptr(counts), counts.numel(), int(extra), lib.ptr(cu))
+    return cu
+
+
+def ragged_pack(x, mask, cu, total):
+    """x [B,n,D], mask [B,n-1], cu [B+1] -> (packed [total,D], row_src [total] int32 = source token of every packed row)."""
+    _f32(x), _f32(mask)
+    B, n, D = x.shape
+    out = torch.empty((total, D), dtype=torch.float32, device=x.device)
+    src = torch.empty((total,), dtype=torch.int32, device=x.device)
+    lib.call("d2s_ragged_pack", lib.ptr(x), lib.ptr(mask), lib.ptr(cu), lib.ptr(out), lib.ptr(src), B, n, D)
+    return out, src
+
+
+def mask_row_weights(mask):
+    m = _f32(mask).reshape(-1)
+    w = torch.empty_like(m)
+    lib.call("d2s_mask_row_weights", lib.ptr(m), m.numel(), lib.ptr(w))
+    return w
+
+
+def dense_mask_agreement(a, b):
+    B, T = a.shape
+    out = torch.empty((B,), dtype=torch.float32, device=a.device)
+    lib.call("d2s_dense_mask_agreement", lib.ptr(_f32(a)), lib.ptr(_f32(b)), B, T, lib.ptr(out))
+    return out
+
+
+def patch_keep_mask(kept, N):
+    """visualizations.py:18-26: kept ids [B,k] -> int64 mask [B,N] in token order (1 = kept)."""
+    assert kept.dtype == torch.int64 and kept.is_contiguous()
+    B, k = kept.shape
+    mask = torch.empty((B, N), dtype=torch.int64, device=kept.device)
+    lib.call("d2s_patch_keep_mask", lib.ptr(kept) if k else None, B, k, N, lib.ptr(mask))
+    return mask
+
+
+def compose_ids(prev, rel):
+    """stage-relative ids -> the coordinates `prev` is expressed in: out[b,j] = prev[b, rel[b,j]]."""
+    B, k = rel.shape
+    out = torch.empty_like(rel)
+    lib.call("d2s_compose_ids", lib.ptr(prev.contiguous()), prev.shape[1], lib.ptr(rel.contiguous()), k, lib.ptr(out), B)
+    return out
+
+
+def attn_policy_fwd(qkv, policy, B, n, H, scale, eps=1e-6, want_cls=False):
+    out = torch.empty((B * n, H * 64), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device)
+    cinv = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device)
+    cls_row = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device) if want_cls else None
+    lib.call("d2s_attn_policy_fwd_f32", lib.ptr(qkv), lib.ptr(_f32(policy)), lib.ptr(out), lib.ptr(lse), lib.ptr(cinv), lib.ptr(cls_row),
+             B, n, H, float(scale), float(eps))
+    return out, lse, cinv, cls_row
+
+
+def attn_policy_bwd(qkv, policy, out, dout, lse, cinv, B, n, H, scale):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device)
+    lib.call("d2s_attn_policy_bwd_f32", lib.ptr(qkv), lib.ptr(policy), lib.ptr(out), lib.ptr(dout), lib.ptr(lse), lib.ptr(cinv),
+             lib.ptr(dqkv), lib.ptr(delta), B, n, H, float(scale))
+    return dqkv
+
+
+def attn_varlen_fwd(qkv, cu, B, total, max_n, H, scale, want_cls=False):
+    out = torch.empty((total, H * 64), dtype=torch.float32, device=qkv.device)
+    cls_row = torch.empty((H, total), dtype=torch.float32, device=qkv.device) if want_cls else None
+    lib.call("d2s_attn_varlen_fwd_f32", lib.ptr(qkv), lib.ptr(cu), lib.ptr(out), lib.ptr(cls_row), B, total, max_n, H, float(scale))
+    return out, cls_row
 
 
 def sum_scalar(v, scale=1.0):

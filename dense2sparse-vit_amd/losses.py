@@ -6,6 +6,11 @@ Differences that are deliberate and documented:
     metrics values are 0-d tensors, `float(v)` reads them.
   * the kl_div and mse mask losses, hard-label and soft-target (mixup) cross entropy are on the accelerated path; the reference's bce
     branch is broken as written (undefined `args` / `self.mask_criterions`, losses.py:57-58).
+  * dynamic keep ratio (args.patch_score_threshold set): the reference's losses cannot run on that path (MaskLoss iterates over the
+    batch dimension of the mask tensor it is handed, losses.py:81; BackboneLoss indexes with a float row and an undefined `C`,
+    :216-218).  The fix built here keeps their intent: no token is removed in training, so every stage's KL runs over all N tokens
+    against the un-gathered teacher target and its accuracy compares the two THRESHOLD masks (student scores vs teacher target under
+    the same cumulative rule); the token distillation term is the mean over the tokens the last stage's mask keeps.
 """
 import torch
 
@@ -22,15 +27,34 @@ class MaskLoss(torch.nn.Module):
         if self.loss_type not in ("kl_div", "mse"):
             raise NotImplementedError("mask_loss_type 'kl_div' (losses.py:75-96) and 'mse' (:61-73) are on the accelerated path; the "
                                       "reference's 'bce' branch is broken as written (:57-58)")
+        self.patch_score_threshold = getattr(args, "patch_score_threshold", None)
         self.count = 1
         self.running_loss = 0
         self.runnings_accs = [0 for _ in self.keep_ratios]
+
+    def _forward_threshold(self, pred_logits, target, keep_masks, mask_accs):
+        """Dynamic keep ratio: every stage scores all N tokens (nothing was gathered), see the module docstring."""
+        B, T = target.shape
+        mask_loss = 0
+        with torch.no_grad():
+            gt_mask, _ = ops.select_threshold(target, float(self.patch_score_threshold))
+        for i in range(len(keep_masks)):
+            if self.loss_type == "mse":
+                mask_loss = mask_loss + DF.RowLossFn.apply(pred_logits[i], ops.MSE_TARGET, target, None, None, B * T / 100.0)
+                continue
+            with torch.no_grad():
+                mask_accs[i] = ops.sum_scalar(ops.dense_mask_agreement(keep_masks[i].contiguous(), gt_mask), 1.0 / float(B * T))
+            mask_loss = mask_loss + DF.RowLossFn.apply(pred_logits[i], ops.KL_PROB_TARGET, target, None, None, B)
+        return mask_loss
 
     def forward(self, pred_logits, cls_attn_weights, kept_token_idx, metrics):
         target = ops.teacher_target(cls_attn_weights.contiguous())             # losses.py:76-79
         B = target.shape[0]
         mask_loss = 0
         mask_accs = [0 for _ in self.keep_ratios]
+        if self.patch_score_threshold is not None:
+            mask_loss = self._forward_threshold(pred_logits, target, kept_token_idx, mask_accs)
+            kept_token_idx = []
         for i in range(len(kept_token_idx)):
             if i > 0:
                 ratio = self.keep_ratios[i] / self.keep_ratios[i - 1]
@@ -63,9 +87,7 @@ class BackboneLoss(torch.nn.Module):
     def __init__(self, args):
         super().__init__()
         self.soft_targets = getattr(args, "mixup", 0.) > 0.      # losses.py:170-174: SoftTargetCrossEntropy under mixup, else hard labels
-        if getattr(args, "patch_score_threshold", None) is not None:
-            raise NotImplementedError("patch_score_threshold path is broken in the reference (losses.py:216-218)")
-        self.patch_score_threshold = None
+        self.patch_score_threshold = getattr(args, "patch_score_threshold", None)
         self.count = 1
         self.running_loss = 0
         self.running_cls_loss = 0
@@ -81,8 +103,14 @@ class BackboneLoss(torch.nn.Module):
             cls_loss = DF.RowLossFn.apply(logits_s, ops.CE_LABEL, None, None, train_labels.contiguous(), B)      # :196
         cls_kl_loss = DF.RowLossFn.apply(logits_s, ops.KL_LOGIT_TARGET, logits_t.detach(), None, None, B)       # :198-203
         rows = token_s.shape[0] * token_s.shape[1]
-        # teacher tokens gathered with the LAST stage's stage-relative ids, exactly like losses.py:212
-        token_kl_loss = DF.RowLossFn.apply(token_s, ops.KL_LOGIT_TARGET, token_t.detach(), kept_token_idx[-1], None, rows)   # :218-225
+        if self.patch_score_threshold is not None:
+            # the intent of losses.py:216-225: distil only the tokens the last stage keeps; student and teacher both still hold all N
+            # tokens, so the pairing is positional and 'batchmean' becomes the mean over the kept rows (weights = mask / count)
+            w = ops.mask_row_weights(kept_token_idx[-1].detach().contiguous())
+            token_kl_loss = DF.RowLossFn.apply(token_s, ops.KL_LOGIT_TARGET, token_t.detach(), None, None, 1.0, w)
+        else:
+            # teacher tokens gathered with the LAST stage's stage-relative ids, exactly like losses.py:212
+            token_kl_loss = DF.RowLossFn.apply(token_s, ops.KL_LOGIT_TARGET, token_t.detach(), kept_token_idx[-1], None, rows)   # :218-225
         backbone_loss = cls_loss + cls_kl_loss + token_kl_loss
         self.running_loss = self.running_loss + backbone_loss.detach()
         self.running_cls_loss = self.running_cls_loss + cls_loss.detach()

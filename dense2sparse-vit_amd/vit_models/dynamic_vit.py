@@ -40,6 +40,20 @@ def batch_index_select(x, idx):
     raise NotImplementedError
 
 
+def patch_drop_mask(kept_token_indices, num_patches):
+    """The kept / dropped mask reconstruction of the reference's visual outputs (visualizations.py:18-26: scatter ones for the kept
+    ids, zeros for the dropped ones) for every stage, in the coordinates of the ORIGINAL patch grid: stage i's ids are relative to the
+    tokens that survived stage i-1, so they are first composed with the previous stages' ids.
+    kept_token_indices: list of int64 [B, k_i] (model.kept_token_indices) -> list of int64 [B, num_patches] 0/1 masks (1 = kept)."""
+    from d2s import ops
+    masks, absolute = [], None
+    for ids in kept_token_indices:
+        ids = ids.contiguous()
+        absolute = ids if absolute is None else ops.compose_ids(absolute, ids)
+        masks.append(ops.patch_keep_mask(absolute, num_patches))
+    return masks
+
+
 class Mlp(nn.Module):
     """:159-175."""
 
@@ -70,16 +84,16 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
 
     def softmax_with_policy(self, attn, policy, eps=1e-6):
-        """:195-214 on a materialised score tensor (the fused attention kernels do not take a policy yet)."""
+        """:195-214 on a materialised score tensor (stand-alone operator; Block / Attention.forward use the fused form)."""
         return DF.PolicySoftmaxFn.apply(attn, policy, eps)
 
     def forward(self, x, policy=None, return_cls_attn=False):
-        if policy is not None:
-            raise NotImplementedError("policy-masked fused attention (patch_score_threshold training path) is not built: the "
-                                      "reference path that needs it is broken end to end (dynamic_vit.py:936, losses.py:216-218)")
         B, N, C = x.shape
         qkv = DF.LinearFn.apply(x.reshape(B * N, C), self.qkv.weight, self.qkv.bias, None)
-        o, cls_row = DF.AttnCoreFn.apply(qkv, B, N, self.num_heads, self.scale, bool(return_cls_attn))
+        if policy is not None:      # :229 softmax_with_policy, fused into the attention pass
+            o, cls_row = DF.AttnCoreFn.apply(qkv, B, N, self.num_heads, self.scale, bool(return_cls_attn), DF.as_policy(policy, B, N))
+        else:
+            o, cls_row = DF.AttnCoreFn.apply(qkv, B, N, self.num_heads, self.scale, bool(return_cls_attn))
         o = DF.LinearFn.apply(o, self.proj.weight, self.proj.bias, None).reshape(B, N, C)
         return (o, cls_row) if return_cls_attn else o
 
@@ -98,14 +112,23 @@ class Block(nn.Module):
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
-    def forward(self, x, policy=None, return_cls_attn=False):
-        if policy is not None:
-            raise NotImplementedError("policy-masked attention (patch_score_threshold) is not on the accelerated hot path")
+    def _params(self):
         a, m = self.attn, self.mlp
-        y, cls_row = DF.BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
-                                      self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
-                                      a.num_heads, self.norm1.eps, bool(return_cls_attn), a.scale)
+        return (self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+                self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
+
+    def forward(self, x, policy=None, return_cls_attn=False):
+        a = self.attn
+        extra = () if policy is None else (DF.as_policy(policy, x.shape[0], x.shape[1]),)     # :263-283 with policy -> fused policy softmax
+        y, cls_row = DF.BlockFn.apply(x, *self._params(), a.num_heads, self.norm1.eps, bool(return_cls_attn), a.scale, *extra)
         return (y, cls_row) if return_cls_attn else y
+
+    def forward_ragged(self, xp, cu_seqlens, B, max_n, return_cls_attn=False):
+        """The block on a ragged packed batch [total, D] (inference with a dynamic keep ratio, :935-949).  Forward only."""
+        a = self.attn
+        y, cls_rows = DF.ragged_block_forward(xp, cu_seqlens, B, max_n, self._params(), a.num_heads, self.norm1.eps, a.scale,
+                                              want_cls=bool(return_cls_attn))
+        return (y, cls_rows) if return_cls_attn else y
 
 
 class PatchEmbed(nn.Module):
@@ -295,9 +318,6 @@ class VisionTransformerDiffPruning(_ViTBase):
         super().__init__()
         self._build_trunk(img_size, patch_size, in_chans, num_classes, embed_dim, depth, num_heads, mlp_ratio, qkv_bias, qk_scale,
                           representation_size, drop_rate, attn_drop_rate, drop_path_rate, hybrid_backbone, norm_layer)
-        if patch_score_threshold is not None:
-            raise NotImplementedError("patch_score_threshold (dynamic keep ratio) is broken in the reference (dynamic_vit.py:936, "
-                                      "losses.py:216-218) and not on the accelerated hot path (SURVEY 8f.3)")
         if early_exit:      # :752-758: the head is created (state-dict keys, 'early_exit' parameter group) but no forward path of the
             # reference ever calls it, so its parameters never receive a gradient and the optimiser never moves them
             self.early_exit_head = nn.Sequential((norm_layer or partial(nn.LayerNorm, eps=1e-6))(embed_dim),
@@ -321,7 +341,8 @@ class VisionTransformerDiffPruning(_ViTBase):
         self.dropped_token_indices = None
         self.pred_logits = []
         self.patch_score_threshold = patch_score_threshold
-        self.keep_ratios = self.min_keep_ratio = self.avg_keep_ratio = self.max_keep_ratio = None
+        self.keep_ratios = None          # :886 / :941 - per-image kept fraction of the last thresholded stage (device tensor)
+        self.cu_seqlens = self.ragged_row_src = None     # ragged inference: packed-row offsets per image / source token of each row
         self.unpruned = False
         self.distill = distill
         self.pruning_loc, self.token_ratio = pruning_loc, token_ratio
@@ -334,7 +355,23 @@ class VisionTransformerDiffPruning(_ViTBase):
         trunc_normal_(self.cls_token, std=.02)
         self.apply(self._init_weights)
 
+    # :887-889 / :942-944 read the minimum / mean / maximum kept fraction with three .item() calls (three device syncs per stage per
+    # step); here they are derived from `keep_ratios` only when a caller looks at them
+    @property
+    def min_keep_ratio(self):
+        return None if self.keep_ratios is None else float(self.keep_ratios.min())
+
+    @property
+    def avg_keep_ratio(self):
+        return None if self.keep_ratios is None else float(self.keep_ratios.mean())
+
+    @property
+    def max_keep_ratio(self):
+        return None if self.keep_ratios is None else float(self.keep_ratios.max())
+
     def forward(self, x, stacked_cls_attn_weights=None):
+        if self.patch_score_threshold is not None:
+            return self._forward_threshold(x)
         x = self._embed(x)                                                  # :816-824
         self.num_kept_tokens, self.cls_attns, self.pred_logits = [], [], []
         self.kept_token_indices, self.dropped_token_indices = [], []
@@ -357,6 +394,82 @@ class VisionTransformerDiffPruning(_ViTBase):
         if self.training:
             return logits, features, self.pred_logits, self.kept_token_indices   # :1013
         return logits, self.cls_attns, self.pred_logits, self.kept_token_indices  # :1015
+
+    def _forward_threshold(self, x):
+        """Dynamic keep ratio (patch_score_threshold is set).
+
+        Training (:880-894, :981-983, :1010-1011): no token is removed.  Each pruning stage turns its keep probabilities into a 0/1 mask
+        (tokens whose ascending cumulative probability exceeds the threshold are kept), and that stage's block and every later block
+        attend through Attention.softmax_with_policy with the mask as key policy; the blocks before the first stage use the all-ones
+        policy, exactly as the reference does.  A later stage REPLACES the mask (the reference does not intersect them).
+        Returns (logits, features [B,N,D], [pred_logits per stage], [keep mask [B,N] per stage]) - lists, where the reference returns the
+        last stage's tensors only (:1011): the per-stage mask loss needs every stage.
+
+        Inference (:935-949, with the reference's undefined `score` read as `pred_score`): the kept tokens of every image are packed
+        into one ragged batch [total, D] (`cu_seqlens` [B+1] gives each image's rows) and the remaining blocks run on it - LayerNorm
+        and GEMMs over all packed rows, attention per image.  One pruning stage (the reference's second stage scatters an n_kept-long
+        mask into an N-long buffer and cannot run).  Returns (logits, [cls rows: dense [B,H,N] before the stage, packed [H,total]
+        after it], [pred_logits], [keep mask [B,N]])."""
+        from d2s import ops
+        thr = float(self.patch_score_threshold)
+        x = self._embed(x)
+        B, n, D = x.shape
+        N = n - 1
+        self.num_kept_tokens, self.cls_attns, self.pred_logits = [], [], []
+        self.kept_token_indices, self.dropped_token_indices = [], []       # here: per-stage keep masks / their complements
+        self.cu_seqlens = self.ragged_row_src = None
+        p_count = 0
+        if self.training:
+            policy = torch.ones((B, n), dtype=torch.float32, device=x.device)       # :830,839
+            for i, blk in enumerate(self.blocks):
+                if self.grad_ready_hook is not None and x.requires_grad:
+                    x.register_hook(lambda g, i=i, cb=self.grad_ready_hook: (cb(i), None)[1])
+                if i in self.pruning_loc:
+                    pred_logits, pred_score = self.score_predictor[p_count].forward_tokens(x)      # :855
+                    policy, counts = ops.select_threshold(pred_score.detach().contiguous(), thr, lead=1)   # :881-893 -> [1, mask]
+                    self.keep_ratios = counts.float() / N                                          # :886
+                    self.pred_logits.append(pred_logits)
+                    self.kept_token_indices.append(policy[:, 1:])
+                    self.dropped_token_indices.append(1.0 - policy[:, 1:])
+                    p_count += 1
+                x = blk(x, policy=policy)                                                          # :894 / :983
+            logits, features = self._head(x)
+            return logits, features, self.pred_logits, self.kept_token_indices
+        if len(self.pruning_loc) > 1:
+            raise NotImplementedError("ragged inference with a dynamic keep ratio supports one pruning stage: the reference's second "
+                                      "stage scatters an n_kept-long mask into an N-long buffer (dynamic_vit.py:945-946) and cannot run")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("ragged inference is forward only: call it under torch.no_grad()")
+        cu = None
+        for i, blk in enumerate(self.blocks):
+            if i in self.pruning_loc:
+                pred_logits, pred_score = self.score_predictor[p_count].forward_tokens(x)
+                mask, counts = ops.select_threshold(pred_score.contiguous(), thr)                  # :936-938 (score := pred_score)
+                self.keep_ratios = counts.float() / N                                              # :941
+                self.pred_logits.append(pred_logits)
+                self.kept_token_indices.append(mask)
+                self.dropped_token_indices.append(1.0 - mask)
+                cu = ops.ragged_offsets(counts, extra=1)
+                total = int(cu[-1])          # the one device sync of the ragged path: the packed row count sizes every later launch
+                x, self.ragged_row_src = ops.ragged_pack(x, mask, cu, total)                       # :947-948
+                self.cu_seqlens = cu
+                x = blk.forward_ragged(x, cu, B, n)                                                # :949 blk(x)
+                p_count += 1
+            elif cu is None:
+                x, cls_attn = blk(x, return_cls_attn=True)                                         # :987
+                self.cls_attns.append(cls_attn[:, :, 1:])
+            else:
+                x, cls_rows = blk.forward_ragged(x, cu, B, n, return_cls_attn=True)
+                self.cls_attns.append(cls_rows)             # packed [H, total]; image b's CLS row is columns cu[b] .. cu[b+1]
+        if cu is None:
+            logits, features = self._head(x)
+            return logits, self.cls_attns, self.pred_logits, self.kept_token_indices
+        total = x.shape[0]
+        xn, _, _ = ops.layernorm_fwd(x, ops.contiguous_map(total, D), self.norm.weight, self.norm.bias, total, D, self.norm.eps, stats=False)
+        cls_rows = ops.gather_rows_i32(xn, cu, B)                                                  # :996 x[:, 0] of every image
+        logits = ops.linear_fwd(cls_rows, self.head.weight, self.head.bias)
+        self.ragged_features = xn
+        return logits, self.cls_attns, self.pred_logits, self.kept_token_indices
 
     def forward_cls_attn(self, x):
         """:1018-1033."""

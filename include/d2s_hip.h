@@ -148,12 +148,44 @@ int d2s_gather_renorm(const float* in, const long long* ids, float* out, int B, 
  * by the kept ids, losses.py:212). */
 int d2s_kl_rows(const float* s, long s_rpg, long s_gs, long s_rs, long s_off, const float* t, long t_rpg, long t_gs, long t_rs,
                 long t_off, const long long* t_ids, const long long* labels, float* loss_row, float* grad, long rows, int C,
-                int mode, d2s_stream_t stream);
+                int mode, const float* row_weight, d2s_stream_t stream);   /* row_weight [rows] or NULL: scales each row's loss and gradient */
 int d2s_sum_scalar(const float* v, long n, float scale, float* out, d2s_stream_t stream);
 int d2s_scale_by_scalar(const float* x, const float* gscalar, float scale, float* y, long n, d2s_stream_t stream);
 /* losses.py:96,121-164: number of positions on which two top-k masks (as id lists) agree */
 int d2s_mask_agreement(const long long* ids_a, const long long* ids_b, int B, int T, int k, float* agree, d2s_stream_t stream);
 int d2s_act_grad(const float* g, const float* z, float* out, long n, int kind, d2s_stream_t stream);
+
+/* ---- dynamic keep ratio (--patch-score-threshold) -------------------------------------------------------
+ * vit_models/dynamic_vit.py:880-891: val, idx = sort(pred_score); th = cumsum(val) > threshold; mask = scatter(idx, th).
+ * probs [B,T] -> mask (1.0 = kept) with token i of image b at mask[b * ld + lead + i] and the `lead` first entries of each row set
+ * to 1 (lead = 1, ld = T + 1: the attention policy row [CLS, tokens] of :892-893); counts [B] (may be NULL).  Stable ascending order,
+ * sequential fp32 running sum (torch.cumsum's order on the CPU). */
+int d2s_select_threshold(const float* probs, int B, int T, float threshold, float* mask, long ld, int lead, int* counts,
+                         d2s_stream_t stream);
+/* dst[r] = src[idx[r]] for rows of D floats (the CLS rows of a ragged packed batch, idx = cu_seqlens) */
+int d2s_gather_rows_i32(const float* src, const int* idx, float* dst, int rows, int D, d2s_stream_t stream);
+/* :935-949 (inference keeps only the selected tokens; one length per image): cu[0] = 0, cu[b+1] = cu[b] + counts[b] + extra */
+int d2s_ragged_offsets(const int* counts, int B, int extra, int* cu_seqlens, d2s_stream_t stream);
+/* x [B,n,D] (row 0 = CLS, always kept), mask [B,n-1] -> out [cu[B], D]; row_src [cu[B]] (optional) = source token of each row */
+int d2s_ragged_pack(const float* x, const float* mask, const int* cu_seqlens, float* out, int* row_src, int B, int n, int D,
+                    d2s_stream_t stream);
+/* weights[r] = mask[r] / sum(mask): the token-distillation term over the kept tokens only (the build's fix for losses.py:216-218) */
+int d2s_mask_row_weights(const float* mask, long rows, float* weights, d2s_stream_t stream);
+/* agree[b] = number of positions where two dense 0/1 masks [B,T] agree (mask accuracy, losses.py:96 for threshold masks) */
+int d2s_dense_mask_agreement(const float* mask_a, const float* mask_b, int B, int T, float* agree, d2s_stream_t stream);
+/* visualizations.py:18-26: kept ids [B,k] of one stage -> int64 0/1 mask [B,N] in token order */
+int d2s_patch_keep_mask(const long long* kept, int B, int k, int N, long long* mask, d2s_stream_t stream);
+/* out[b,j] = prev[b, rel[b,j]]: stage-relative kept ids expressed in the previous stage's coordinates */
+int d2s_compose_ids(const long long* prev, int kp, const long long* rel, int k, long long* out, int B, d2s_stream_t stream);
+/* Attention.forward with policy != None (vit_models/dynamic_vit.py:216-236 + softmax_with_policy :195-214) as one fused pass;
+ * policy [B,n] (1 = kept, entry 0 = CLS); lse [B,H,n] = m + log(l + eps) and cinv [B,H,n] = (eps/n)/(l + eps) feed the backward. */
+int d2s_attn_policy_fwd_f32(const float* qkv, const float* policy, float* out, float* lse, float* cinv, float* cls_row, int B, int n,
+                            int H, float scale, float eps, d2s_stream_t stream);
+int d2s_attn_policy_bwd_f32(const float* qkv, const float* policy, const float* out, const float* dout, const float* lse,
+                            const float* cinv, float* dqkv, float* delta_ws, int B, int n, int H, float scale, d2s_stream_t stream);
+/* ragged packed attention forward (inference): qkv [total,3,H,64], image b = rows cu[b]..cu[b+1]; cls_row (optional) [H,total] */
+int d2s_attn_varlen_fwd_f32(const float* qkv, const int* cu_seqlens, float* out, float* cls_row, int B, int total, int max_n, int H,
+                            float scale, d2s_stream_t stream);
 
 /* ---- BatchNorm1d over the token rows of [R, C] (the --predictor-bn variant: vit_models/dynamic_vit.py:350-367 BatchNormLayer) ------ */
 size_t d2s_batchnorm_workspace_bytes(long R, int C);

@@ -265,6 +265,101 @@ def student_forward(sd, x, cfg, training=True, bn_state=None):
     return (logits, cls_attns, pred_logits, kept_all), aux
 
 
+# --------------------------------------------------------------------------------------------------
+# dynamic keep ratio (--patch-score-threshold), SURVEY 8f rank 3
+# --------------------------------------------------------------------------------------------------
+def select_threshold(keep_probs, threshold):
+    """vit_models/dynamic_vit.py:881-891: ascending sort of the keep probabilities, cumulative sum, keep the tokens whose running sum
+    exceeds the threshold, scattered back to token order.  Returns (mask [B,N] float, counts [B])."""
+    val, idx = torch.sort(keep_probs.detach().clone())
+    th = torch.cumsum(val, dim=-1) > threshold
+    mask = torch.scatter(torch.zeros_like(th), 1, idx, th)     # the reference scatters into torch.empty: every slot is overwritten
+    return mask.float(), th.sum(dim=1)
+
+
+def student_forward_threshold_train(sd, x, cfg, threshold):
+    """VisionTransformerDiffPruning.forward in training mode with patch_score_threshold set (:826-894, :981-983, :993-1011): no token
+    is removed; a stage's mask becomes the key policy of that block and every later block (softmax_with_policy, :195-214), blocks
+    before the first stage use the all-ones policy, a later stage replaces the mask.  Returns (logits, features [B,N,D],
+    [pred_logits per stage], [mask [B,N] per stage]) - the reference returns the LAST stage's pred_logits / mask only (:1011)."""
+    x = embed_tokens(sd, x, cfg)
+    B, n, _ = x.shape
+    policy = torch.ones(B, n, 1, dtype=x.dtype)
+    pred_logits, masks = [], []
+    stage = 0
+    for i in range(cfg["depth"]):
+        if i in cfg["pruning_loc"]:
+            scores, probs = predictor(sd, stage, x[:, 1:], cfg)
+            mask, _ = select_threshold(probs, threshold)
+            policy = torch.cat((torch.ones(B, 1, dtype=x.dtype), mask), dim=1).unsqueeze(-1)
+            pred_logits.append(scores)
+            masks.append(mask)
+            stage += 1
+        x, _ = block(sd, i, x, cfg, policy=policy)
+    x = F.layer_norm(x, (cfg["dim"],), sd["norm.weight"], sd["norm.bias"], cfg["ln_eps"])
+    logits = F.linear(x[:, 0], sd["head.weight"], sd["head.bias"])
+    return logits, x[:, 1:], pred_logits, masks
+
+
+def student_forward_threshold_eval(sd, x, cfg, threshold):
+    """Inference with a dynamic keep ratio (:935-949), one pruning stage, with the reference's undefined `score` read as the stage's
+    keep probabilities and its flat boolean indexing done per image (the reference's reshape(B, -1, D) only exists for equal counts):
+    every image goes on with its CLS token and its own kept tokens.  PARITY UNPINNED (the reference raises NameError here); this is
+    the build's definition, checked per image against the same blocks run densely on the kept subset.
+    Returns (logits [B,C], [normed tokens per image [n_b, D]], pred_logits, mask)."""
+    assert len(cfg["pruning_loc"]) == 1
+    x = embed_tokens(sd, x, cfg)
+    loc = cfg["pruning_loc"][0]
+    for i in range(loc):
+        x, _ = block(sd, i, x, cfg)
+    scores, probs = predictor(sd, 0, x[:, 1:], cfg, training=False)
+    mask, _ = select_threshold(probs, threshold)
+    logits, feats = [], []
+    for b in range(x.shape[0]):
+        keep = torch.cat((torch.ones(1, dtype=torch.bool), mask[b] > 0))
+        xb = x[b:b + 1, keep]
+        for i in range(loc, cfg["depth"]):
+            xb, _ = block(sd, i, xb, cfg)
+        xb = F.layer_norm(xb, (cfg["dim"],), sd["norm.weight"], sd["norm.bias"], cfg["ln_eps"])
+        logits.append(F.linear(xb[:, 0], sd["head.weight"], sd["head.bias"]))
+        feats.append(xb[0])
+    return torch.cat(logits, dim=0), feats, scores, mask
+
+
+def mask_loss_threshold(pred_logits, cls_attn, masks, threshold):
+    """The build's fix of MaskLoss for the dynamic-keep-ratio path (the reference's loop runs over the batch dimension of the mask
+    tensor, losses.py:81, and cannot run): per stage KL(log_softmax(scores) || log target) over ALL N tokens (nothing was gathered),
+    accuracy = agreement of the stage's mask with the teacher target thresholded by the same rule.  PARITY UNPINNED."""
+    target = teacher_target(cls_attn)
+    gt, _ = select_threshold(target, threshold)
+    loss, accs = 0, []
+    for i in range(len(masks)):
+        loss = loss + F.kl_div(F.log_softmax(pred_logits[i], dim=-1), torch.log(target), log_target=True, reduction="batchmean")
+        accs.append(torch.sum(masks[i] == gt) / gt.numel())
+    return loss, accs
+
+
+def backbone_loss_threshold(logits_s, token_s, logits_t, token_t, masks, labels):
+    """The build's fix of BackboneLoss' threshold branch (losses.py:216-218: undefined `C`, float-row indexing): the token KL over
+    the tokens the LAST stage keeps, paired by position, averaged over the kept rows.  PARITY UNPINNED."""
+    cls_loss = F.cross_entropy(logits_s, labels)
+    cls_kl = F.kl_div(F.log_softmax(logits_s, dim=-1), F.log_softmax(logits_t, dim=-1), reduction="batchmean", log_target=True)
+    keep = masks[-1].reshape(-1) > 0
+    C = token_t.shape[-1]
+    ts, tt = token_s.reshape(-1, C)[keep], token_t.reshape(-1, C)[keep]
+    tok_kl = F.kl_div(F.log_softmax(ts, dim=-1), F.log_softmax(tt, dim=-1), reduction="batchmean", log_target=True)
+    return cls_loss + cls_kl + tok_kl, cls_loss, cls_kl, tok_kl
+
+
+def patch_drop_mask(kept, dropped):
+    """visualizations.py:18-26: kept / dropped id lists of one stage -> 0/1 mask in token order."""
+    token_idx = torch.cat((kept, dropped), dim=1)
+    srt = torch.cat((torch.ones_like(kept), torch.zeros_like(dropped)), dim=1)
+    out = torch.empty_like(srt)
+    out.scatter_(dim=1, index=token_idx.long(), src=srt)
+    return out
+
+
 def teacher_forward(sd, x, cfg):
     """VisionTransformerTeacher.forward, vit_models/dynamic_vit.py:1150-1176:
     (logits, tokens[B,N,D], cls_attn[B,depth,H,N+1]) - CLS rows detached (:1165)."""

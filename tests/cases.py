@@ -48,6 +48,16 @@ MODEL_CASES = {
                         batch=1, seed=51),
 }
 
+# Dynamic keep ratio (--patch-score-threshold): name -> dict(cfg, batch, seed, threshold).  The keep probabilities of a stage sum to 1
+# over the N tokens, so the threshold is the probability mass of the lowest-scored tokens that gets dropped.
+THRESHOLD_CASES = {
+    "micro_thr1": dict(cfg=O.make_cfg(img_size=64, dim=128, depth=4, heads=2, num_classes=10, pruning_loc=(1,), token_ratio=(0.5,)),
+                       batch=3, seed=61, threshold=0.3),
+    "micro_thr2": dict(cfg=O.make_cfg(img_size=64, dim=128, depth=4, heads=2, num_classes=10, pruning_loc=(1, 2), token_ratio=(0.5, 0.3)),
+                       batch=3, seed=62, threshold=0.45),
+    "small_thr": dict(cfg=O.make_cfg(dim=384, depth=12, heads=6, pruning_loc=(3,), token_ratio=(0.5,)), batch=2, seed=63, threshold=0.35),
+}
+
 # tag -> (b, nS, d, k, sigma)
 PTK_CASES = {
     "small": (2, 16, 12, 4, 0.05),

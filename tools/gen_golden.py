@@ -211,6 +211,79 @@ def gen_model_case(dv, losses, name):
           f"kept shapes={[tuple(k_.shape) for k_ in kept]}")
 
 
+def gen_threshold_case(dv, name):
+    """Dynamic keep ratio: the reference's student in TRAINING mode with patch_score_threshold set (dynamic_vit.py:880-894,981-983 -
+    threshold selection + softmax_with_policy attention in every block; this forward runs as written).  Stored: logits, features,
+    the last stage's pred_logits and keep mask (what :1011 returns), the per-image keep ratios, and the parameter gradients of a fixed
+    linear probe of the three differentiable outputs (the reference's own losses cannot run on this path, losses.py:81,216-218).
+    The eval-mode forward of this path raises NameError (`score`, :936) in the reference: recorded, nothing to store."""
+    case = cases.THRESHOLD_CASES[name]
+    cfg = case["cfg"]
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        student = dv.VisionTransformerDiffPruning(
+            img_size=cfg["img_size"], patch_size=cfg["patch"], embed_dim=cfg["dim"], depth=cfg["depth"], num_heads=cfg["heads"],
+            mlp_ratio=cfg["mlp_ratio"], qkv_bias=True, num_classes=cfg["num_classes"], pruning_loc=list(cfg["pruning_loc"]),
+            token_ratio=list(cfg["token_ratio"]), distill=True, topk_selection=True, predictor_loss_type=cfg["loss_type"],
+            patch_score_threshold=case["threshold"])
+    sd_s, _ = cases.make_weights(case)
+    _load_sd(student, sd_s)
+    student.train()
+    x = _t(cases.make_images(case))
+    logits, features, pred_logits, keep_mask = student(x.clone())
+    out = {"logits": _np(logits), "features_slice": _np(features[:, :4, :16]), "features_sum": _np(features.double().sum(dim=(1, 2))),
+           "features_shape": np.array(features.shape), "pred_logits_last": _np(pred_logits), "keep_mask_last": _np(keep_mask),
+           "keep_ratios": _np(student.keep_ratios)}
+    g1 = _t(synth.normal(f"thr/{name}/g1", tuple(logits.shape), seed=case["seed"]))
+    g2 = _t(synth.normal(f"thr/{name}/g2", tuple(features.shape), seed=case["seed"]))
+    g3 = _t(synth.normal(f"thr/{name}/g3", tuple(pred_logits.shape), seed=case["seed"]))
+    student.zero_grad()
+    ((logits * g1).sum() + (features * g2).sum() / features.shape[1] + (pred_logits * g3).sum()).backward()
+    names, norms, heads = [], [], []
+    for n_, p in student.named_parameters():
+        names.append(n_)
+        if p.grad is None:
+            norms.append(-1.0)
+            heads.append(np.zeros(8, np.float32))
+        else:
+            g = p.grad.detach().flatten()
+            norms.append(float(g.double().norm()))
+            h = np.zeros(8, np.float32)
+            h[: min(8, g.numel())] = _np(g[:8])
+            heads.append(h)
+    out["grad_names"], out["grad_norms"], out["grad_heads"] = np.array(names), np.array(norms, np.float64), np.stack(heads)
+    student.eval()
+    try:
+        with torch.no_grad():
+            student(x.clone())
+        out["eval_error"] = np.array("none")
+    except Exception as e:      # NameError: name 'score' is not defined (dynamic_vit.py:936)
+        out["eval_error"] = np.array(f"{type(e).__name__}: {e}")
+    np.savez_compressed(os.path.join(OUT, f"threshold_{name}.npz"), **out)
+    print(f"[golden] threshold_{name}: kept per image {keep_mask.sum(dim=1).tolist()}  eval: {out['eval_error']}")
+
+
+def gen_threshold_selection():
+    """Threshold selection alone on the selection fixtures' probability rows (incl. exact ties and a constant row), with the
+    reference's own four calls (dynamic_vit.py:881-883,891: sort ascending, cumsum, compare, scatter) executed verbatim here because
+    they sit inline in forward() - the model-level threshold fixtures pin the same lines through the reference's class."""
+    out = {}
+    for N in (196, 576, 16):
+        p = _t(cases.make_selection_probs(N))
+        for th in (0.1, 0.35, 0.8):
+            val, idx = torch.sort(p.detach().clone())
+            cum_sum = torch.cumsum(val, dim=-1)
+            t = (cum_sum > th)
+            spatial_mask = torch.empty(p.shape, dtype=torch.bool)
+            spatial_mask = torch.scatter(input=spatial_mask, dim=1, index=idx, src=t)
+            out[f"mask_{N}_{th}"] = _np(spatial_mask)
+            # margin of the decision: distance of the nearest running sum to the threshold (rows below ~1e-6 are rounding-decided)
+            out[f"margin_{N}_{th}"] = _np((cum_sum - th).abs().min(dim=1).values)
+    np.savez_compressed(os.path.join(OUT, "threshold_selection.npz"), **out)
+    print(f"[golden] threshold_selection: {len(out)} arrays")
+
+
 def gen_micro_intermediates(dv, name="micro1"):
     """Every intermediate of the micro geometry: per-op fixtures for LN / attention / MLP / predictor."""
     case = cases.MODEL_CASES[name]
@@ -413,6 +486,9 @@ def main():
     gen_checkpoint_ingestion(dv)
     gen_param_groups(dv)
     gen_mask_loss_mse(losses)
+    gen_threshold_selection()
+    for name in cases.THRESHOLD_CASES:
+        gen_threshold_case(dv, name)
     for name in cases.MODEL_CASES:
         gen_model_case(dv, losses, name)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
