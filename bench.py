@@ -132,7 +132,7 @@ class KernelTimer:
         ops.layernorm_bwd = timed(ops.layernorm_bwd, ("layernorm_bwd", ""),
                                   lambda x, rowmap, dy, w, mean, rstd, dx, add_src, dw, db, rows, D, *a, **kw:
                                   rows * D * 4.0 * (3 + (1 if add_src is not None else 0)))
-        ops.layernorm_fwd = timed(ops.layernorm_fwd, ("layernorm_fwd", ""), lambda x, rowmap, w, b, rows, D, eps: rows * D * 8.0)
+        ops.layernorm_fwd = timed(ops.layernorm_fwd, ("layernorm_fwd", ""), lambda x, rowmap, w, b, rows, D, eps, **kw: rows * D * 8.0)
         ops.adamw_step = timed(ops.adamw_step, ("adamw", ""), lambda params, *a, **kw: params.numel() * 28.0)
 
         orig_wgrad = ops.linear_wgrad

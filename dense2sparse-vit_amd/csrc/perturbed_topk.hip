@@ -113,9 +113,50 @@ __global__ __launch_bounds__(256) void ptk_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// Counter-based standard-normal generator for the perturbation noise (the reference draws torch.normal on the host and copies it to
+// the device, peturbed_topk.py:29): Philox4x32-10 keyed by (seed), counter = element index / 4, four uniforms -> two Box-Muller pairs.
+// Stateless and order independent: element i of the stream is the same whatever the launch shape, so a test can regenerate exactly the
+// numbers a training step consumed.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+__global__ __launch_bounds__(256) void normal_noise_kernel(float* __restrict__ out, long n, unsigned long long seed) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;      // one Philox block = 4 outputs
+    if (q * 4 >= n) return;
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)((unsigned long long)q >> 32), 0u, 0u};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+    float z[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);       // (0, 1)
+        const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float r = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.28318530717958647692f * u2, &sn, &cs);
+        z[2 * h] = r * cs;
+        z[2 * h + 1] = r * sn;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (q * 4 + j < n) out[q * 4 + j] = z[j];
+}
+
 }  // namespace
 
 extern "C" {
+
+// out[0..n) = standard normal numbers of the stream `seed` (device-side replacement of the reference's host torch.normal, :29)
+int d2s_normal_noise(float* out, long n, unsigned long long seed, hipStream_t stream) {
+    if (!out || n <= 0) return D2S_ERR_ARG;
+    const long blocks = ((n + 3) / 4 + 255) / 256;
+    hipLaunchKernelGGL(normal_noise_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, out, n, seed);
+    return d2s_check_launch();
+}
 
 size_t d2s_perturbed_topk_workspace_bytes(int b, int k, int d) { return (size_t)b * k * d * sizeof(int); }
 

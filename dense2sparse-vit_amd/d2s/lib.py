@@ -68,6 +68,7 @@ _SIGS = {
     "d2s_scale_by_scalar": (I, [P, P, F, P, L]),
     "d2s_mask_agreement": (I, [P, P, I, I, I, P]),
     "d2s_act_grad": (I, [P, P, P, L, I]),
+    "d2s_normal_noise": (I, [P, L, ctypes.c_ulonglong]),
     "d2s_perturbed_topk_workspace_bytes": (Z, [I, I, I]),
     "d2s_perturbed_topk_fwd": (I, [P, P, P, I, I, I, I, F, P, Z]),
     "d2s_perturbed_topk_bwd": (I, [P, P, P, P, I, I, I, I, F]),

@@ -418,6 +418,13 @@ def act_grad(g, z, kind):
     return out
 
 
+def normal_noise(shape, seed, device):
+    """Standard-normal tensor from the library's counter-based stream `seed` (no torch RNG, no host copy)."""
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    lib.call("d2s_normal_noise", lib.ptr(out), out.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF)
+    return out
+
+
 def perturbed_topk_fwd(x, noise, k, sigma):
     b, d = x.shape
     nS = noise.shape[1]

@@ -7,14 +7,21 @@ from d2s import functional as DF
 
 class PerturbedTopKFunction:
     """apply(x, k, num_samples, sigma, noise=None) -> indicators [b, k, d]  (peturbed_topk.py:18-69; backward :72-80).
-    The reference draws the noise from torch's global RNG on the CPU (:29); here it is an explicit input so that
-    results are reproducible, and when omitted it is drawn on the device from torch's generator."""
+    The reference draws the noise from torch's global RNG on the CPU and copies it to the device (:29); here it is an explicit input so
+    that results are reproducible, and when omitted it is generated ON the device by the library's counter-based stream
+    (d2s_normal_noise; `seed` selects the stream, successive calls without a seed advance a module-level counter)."""
+
+    _calls = 0
 
     @staticmethod
-    def apply(x, k, num_samples=500, sigma=0.05, noise=None):
+    def apply(x, k, num_samples=500, sigma=0.05, noise=None, seed=None):
+        from d2s import ops
         b, d = x.shape
         if noise is None:
-            noise = torch.randn((b, num_samples, d), dtype=torch.float32, device=x.device)
+            if seed is None:
+                PerturbedTopKFunction._calls += 1
+                seed = 0x9E3779B97F4A7C15 * PerturbedTopKFunction._calls
+            noise = ops.normal_noise((b, num_samples, d), seed, x.device)
         return DF.PerturbedTopKFn.apply(x, noise, int(k), float(sigma))
 
 
@@ -23,5 +30,5 @@ class PerturbedTopK(nn.Module):
         super().__init__()
         self.num_samples, self.sigma, self.k = num_samples, sigma, k
 
-    def __call__(self, x, current_sigma=0.05, noise=None):
-        return PerturbedTopKFunction.apply(x, self.k, self.num_samples, current_sigma, noise)
+    def __call__(self, x, current_sigma=0.05, noise=None, seed=None):
+        return PerturbedTopKFunction.apply(x, self.k, self.num_samples, current_sigma, noise, seed)

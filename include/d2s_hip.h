@@ -131,6 +131,9 @@ int d2s_performer_attn_bwd(const float* kqv, const float* w, const float* y, con
                            size_t workspace_bytes, d2s_stream_t stream);
 
 /* ---- perturbed top-k (vit_models/peturbed_topk.py:16-80), noise injected ------------------------------------------ */
+/* peturbed_topk.py:29 draws torch.normal on the host; this fills out[0..n) with standard normals of the counter-based stream `seed`
+ * (Philox4x32-10 + Box-Muller; element i does not depend on the launch shape) so that production needs no host RNG / H2D copy */
+int d2s_normal_noise(float* out, long n, unsigned long long seed, d2s_stream_t stream);
 size_t d2s_perturbed_topk_workspace_bytes(int b, int k, int d);
 int d2s_perturbed_topk_fwd(const float* x, const float* noise, float* indicators, int b, int nS, int d, int k, float sigma,
                            void* workspace, size_t workspace_bytes, d2s_stream_t stream);

@@ -351,7 +351,7 @@ def test_gemm_small_grid_split_k_epilogues(ops, M, N, K):
     w = torch.randn(N, K, generator=g) * 0.05
     b = torch.randn(N, generator=g)
     r = torch.randn(M, N, generator=g)
-    need = ops.lib.query("d2s_gemm_f32_workspace_bytes", 0, M, N, K)
+    need = ops.lib.query("d2s_gemm_f32_workspace_bytes", 0, M, N, K, ops.GEMM_EXACT)
     assert need > 0, "this shape is expected to take the split-K path"
     ref = (x.double() @ w.double().t())
     d = _dev()

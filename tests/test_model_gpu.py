@@ -236,6 +236,65 @@ def test_optimizer_warmup_to_full_transition():
     assert worst <= 2 * nsteps * hp["lr"] * 1.01
 
 
+def test_normal_noise_stream():
+    """d2s_normal_noise (device-side replacement of the reference's host torch.normal, peturbed_topk.py:29): deterministic per seed,
+    independent of the launch shape (a prefix of a longer stream equals the shorter stream), different seeds differ, moments of N(0,1)."""
+    from d2s import ops
+    dev = torch.device("cuda:0")
+    a = ops.normal_noise((1 << 20,), 1234, dev)
+    b = ops.normal_noise((1 << 20,), 1234, dev)
+    c = ops.normal_noise((1000003,), 1234, dev)
+    d = ops.normal_noise((1 << 20,), 1235, dev)
+    assert torch.equal(a, b) and torch.equal(a[:1000003], c) and not torch.equal(a, d)
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.var()) - 1.0) < 1e-2 and bool(torch.isfinite(a).all())
+    assert abs(float((a ** 4).mean()) - 3.0) < 0.1 and float(a.abs().max()) > 4.0
+
+
+def test_perturbed_topk_at_reference_size():
+    """peturbed_topk.py:6 - num_samples = 500 - at the headline geometry (b = 128, d = 196, k = 98), noise from the device generator.
+    Checked (a) against the oracle on the first 4 images with the very same noise, (b) through the properties every indicator tensor
+    has: each of the k rows sums to 1, every column sums to <= 1, entries are multiples of 1/nS; (c) timing line."""
+    import vit_models
+    from d2s import ops, synth
+    dev = torch.device("cuda:0")
+    b, nS, d, k, sigma = 128, 500, 196, 98, 0.05
+    x = _t(synth.normal("ptk/full/x", (b, d), std=1.0, seed=3)).to(dev).requires_grad_(True)
+    noise = ops.normal_noise((b, nS, d), 77, dev)
+    ind = vit_models.PerturbedTopKFunction.apply(x, k, nS, sigma, noise)
+    assert tuple(ind.shape) == (b, k, d)
+    rows = ind.detach().sum(dim=2)
+    np.testing.assert_allclose(rows.cpu().numpy(), 1.0, rtol=0, atol=2e-6)
+    assert float(ind.detach().sum(dim=1).max()) <= 1.0 + 2e-6
+    cnt = ind.detach() * nS
+    assert float((cnt - cnt.round()).abs().max()) < 1e-3
+    go = _t(synth.normal("ptk/full/g", (b, k, d), std=1.0, seed=4)).to(dev)
+    ind.backward(go)
+    # oracle on a slice (the one-hot tensor of the reference is 4 * 500 * 98 * 196 * 4 B = 154 MB here, 4.9 GB at b = 128)
+    nb = 4
+    xo = x.detach()[:nb].cpu().requires_grad_(True)
+    oind, ids = O.perturbed_topk_fwd(xo, noise[:nb].cpu(), k, sigma)
+    np.testing.assert_allclose(ind.detach()[:nb].cpu().numpy(), oind.detach().numpy(), rtol=1e-6, atol=0)
+    ogx = O.perturbed_topk_bwd(go[:nb].cpu(), noise[:nb].cpu(), ids, sigma)
+    np.testing.assert_allclose(x.grad[:nb].cpu().numpy(), ogx.numpy(), rtol=2e-4, atol=2e-5)
+    # module form with its own device-side noise: reproducible per seed, rows still sum to one
+    m = vit_models.PerturbedTopK(k, num_samples=nS)
+    o1, o2 = m(x.detach(), current_sigma=sigma, seed=5), m(x.detach(), current_sigma=sigma, seed=5)
+    assert torch.equal(o1, o2)
+    np.testing.assert_allclose(o1.sum(dim=2).cpu().numpy(), 1.0, rtol=0, atol=2e-6)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev[0].record()
+    noise2 = ops.normal_noise((b, nS, d), 78, dev)
+    ev[1].record()
+    ind2 = ops.perturbed_topk_fwd(x.detach(), noise2, k, sigma)
+    ev[2].record()
+    ops.perturbed_topk_bwd(x.detach(), noise2, go, k, sigma)
+    ev[3].record()
+    torch.cuda.synchronize()
+    print(f"[perturbed top-k b={b} nS={nS} d={d} k={k}] noise {ev[0].elapsed_time(ev[1]):.3f} ms, forward {ev[1].elapsed_time(ev[2]):.3f} ms, "
+          f"backward {ev[2].elapsed_time(ev[3]):.3f} ms; reference one-hot tensor avoided: {b * nS * k * d * 4 / 1e9:.1f} GB")
+
+
 @pytest.mark.parametrize("tag", list(cases.PTK_CASES))
 def test_perturbed_topk_parity(tag):
     from d2s import synth
