@@ -113,8 +113,13 @@ def load_golden(name):
 T2T_CASE = dict(img_size=64, dim=128, depth=2, heads=2, mlp_ratio=3.0, num_classes=10, batch=2, seed=41)
 
 
-def make_t2t_weights(tokens_type, pruning_loc=()):
-    c = T2T_CASE
+# BASELINE config 4 at its own geometry: T2T-ViT-14 (t2t_vit.py:182-199: embed_dim 384, depth 14, 6 heads, mlp_ratio 3), 224x224 images:
+# 3136 -> 784 -> 196 tokens through the two token encoders (performer: T2t_vit_14, transformer: T2t_vit_t_14), 1000 classes
+T2T_224_CASE = dict(img_size=224, dim=384, depth=14, heads=6, mlp_ratio=3.0, num_classes=1000, batch=1, seed=43)
+
+
+def make_t2t_weights(tokens_type, pruning_loc=(), case=None):
+    c = case or T2T_CASE
     shapes = O.t2t_param_shapes(c["img_size"], c["dim"], c["depth"], c["heads"], c["mlp_ratio"], c["num_classes"], tokens_type,
                                 pruning_loc=pruning_loc)
     sd = synth.fill_state_dict(shapes, seed=c["seed"], std=0.02, std_overrides={"score_predictor": 0.08, "tokens_to_token": 0.05})
@@ -126,5 +131,6 @@ def make_t2t_weights(tokens_type, pruning_loc=()):
     return sd
 
 
-def make_t2t_images():
-    return synth.images(T2T_CASE["batch"], 3, T2T_CASE["img_size"], seed=T2T_CASE["seed"])
+def make_t2t_images(case=None, batch=None):
+    c = case or T2T_CASE
+    return synth.images(batch or c["batch"], 3, c["img_size"], seed=c["seed"])

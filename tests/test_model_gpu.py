@@ -386,10 +386,10 @@ def test_full_size_train_step_deterministic_and_batch_independent():
     np.testing.assert_allclose(half["cls_attn"].cpu().numpy(), cls_attn[:64].cpu().numpy(), rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("name", ["micro2", "small_k50"])
+@pytest.mark.parametrize("name", HIP_CASES)
 def test_split_gemm_mode_keeps_fp32_parity(name):
-    """GEMM mode 1 (bf16x3 split on the bf16 matrix cores): same assertions as the exact mode - kept ids bit-exact against the
-    reference fixture, logits / losses at the fp32 tolerances."""
+    """GEMM mode 1 (bf16x3 split on the bf16 matrix cores) on EVERY model case of the parity suite: same assertions as the exact mode -
+    kept ids bit-exact against the reference fixture, logits / losses / gradient norms at the fp32 tolerances."""
     from d2s.engine import TrainStep
     from d2s import ops
     dev = torch.device("cuda:0")
@@ -415,8 +415,78 @@ def test_split_gemm_mode_keeps_fp32_parity(name):
     np.testing.assert_allclose(float(info["mask_loss"]), float(g["mask_loss"]), rtol=2e-5)
     np.testing.assert_allclose(float(info["backbone_loss"]), float(g["backbone_loss"]), rtol=2e-5)
     params = dict(student.named_parameters())
+    gate_noise = name == "small_3stage"       # one predictor ReLU sits at |z| = 4.5e-7 (see test_train_step_parity)
     for n, ref_norm in zip([str(s) for s in g["grad_names"]], g["grad_norms"]):
-        np.testing.assert_allclose(float(params[n].grad.double().norm()), ref_norm, rtol=1e-3, atol=1e-6, err_msg=n)
+        np.testing.assert_allclose(float(params[n].grad.double().norm()), ref_norm, rtol=5e-3 if gate_noise else 1e-3, atol=1e-6, err_msg=n)
+
+
+@pytest.mark.parametrize("name", ["small_k50", "small_3stage", "base384_k30"])
+def test_bf16_gemm_mode_model_parity(name):
+    """GEMM mode 2 (bf16 operands, fp32 accumulation, bf16 attention: BASELINE config 5's regime) at model level, with the contract of
+    SURVEY 8c: the predictor tail, softmax and selection stay fp32, so the kept ids must be bit-exact on every image whose k / k+1
+    probability margin (computed from the reference's own scores in the fixture) exceeds twice the perturbation the bf16 arithmetic
+    put on that image's probabilities; images below that are reported, not asserted.  Where the ids agree: logits rtol 2e-2 (atol 2 %
+    of the largest logit), losses rtol 2e-2, every parameter gradient within 10 % in relative L2 of the fp32 oracle gradient (bf16
+    rounding 2^-9 per operand through 12 layers; the measured worst case is printed)."""
+    from d2s.engine import TrainStep
+    from d2s import ops
+    dev = torch.device("cuda:0")
+    case = cases.MODEL_CASES[name]
+    cfg = case["cfg"]
+    g = cases.load_golden("model_" + name)
+    ops.set_gemm_mode(ops.GEMM_BF16)
+    try:
+        student, teacher, sd_s, sd_t = build_models(case, dev)
+        x, y = _t(cases.make_images(case)), _t(cases.make_labels(case))
+        ts = TrainStep(student, teacher, make_args(cfg), warmup_steps=0)
+        student.train()
+        loss, info = ts.forward_losses(x.to(dev), y.to(dev))
+        ts.opt.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_gemm_mode(ops.GEMM_EXACT)
+    B = x.shape[0]
+    same = np.ones(B, bool)          # images whose ids agree with the reference on every stage so far
+    undecided = []
+    for i, kept in enumerate(info["kept"]):
+        ref_scores, got_scores = _t(g[f"pred_logits_{i}"]), info["pred_logits"][i].detach().cpu()
+        p_ref, p_got = torch.softmax(ref_scores, dim=-1), torch.softmax(got_scores, dim=-1)
+        k = kept.shape[1]
+        srt = torch.sort(p_ref, dim=-1, descending=True)[0]
+        margin = (srt[:, k - 1] - srt[:, k]).numpy() if k < srt.shape[1] else np.full(B, np.inf)
+        pert = (p_got - p_ref).abs().max(dim=-1)[0].numpy()
+        eq = (kept.cpu().numpy() == g[f"kept_{i}"]).all(axis=1)
+        for b in range(B):
+            if not same[b]:
+                continue                              # an earlier stage already differs: this stage saw other tokens
+            if margin[b] > 2.0 * pert[b]:
+                assert eq[b], f"stage {i} image {b}: ids differ although margin {margin[b]:.3e} > 2 x perturbation {pert[b]:.3e}"
+            elif not eq[b]:
+                undecided.append((i, b, float(margin[b]), float(pert[b])))
+        same &= eq
+    print(f"[{name} bf16] images with ids equal to the reference on every stage: {int(same.sum())}/{B}; margin-undecided differences: {undecided}")
+    lt_ref = g["logits_t"]
+    np.testing.assert_allclose(info["logits_t"].cpu().numpy(), lt_ref, rtol=2e-2, atol=2e-2 * float(np.abs(lt_ref).max()))
+    if same.all():
+        ls_ref = g["logits_s"]
+        np.testing.assert_allclose(info["logits_s"].detach().cpu().numpy(), ls_ref, rtol=2e-2, atol=2e-2 * float(np.abs(ls_ref).max()))
+        np.testing.assert_allclose(float(info["mask_loss"]), float(g["mask_loss"]), rtol=2e-2)
+        np.testing.assert_allclose(float(info["backbone_loss"]), float(g["backbone_loss"]), rtol=2e-2)
+        osd = {k: _t(v).requires_grad_(True) for k, v in sd_s.items()}
+        ototal, _ = O.train_step_losses(osd, {k: _t(v) for k, v in sd_t.items()}, cfg, x, y)
+        ototal.backward()
+        worst, worst_name = 0.0, ""
+        for n, p in student.named_parameters():
+            og = osd[n].grad
+            if og is None or float(og.double().norm()) < 1e-6:
+                continue
+            err = float((p.grad.detach().cpu().double().flatten() - og.double().flatten()).norm() / og.double().norm())
+            if err > worst:
+                worst, worst_name = err, n
+            np.testing.assert_allclose(float(p.grad.double().norm()), float(og.double().norm()), rtol=1e-1, err_msg=n)
+        print(f"[{name} bf16] worst relative L2 gradient error vs the fp32 oracle: {worst:.3e} ({worst_name})")
+        assert worst < 1e-1, (worst, worst_name)
 
 
 def test_overfit_one_batch():

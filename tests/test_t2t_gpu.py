@@ -153,3 +153,84 @@ def test_pruned_t2t_train_step_matches_oracle_composition():
             continue
         assert p.grad is not None, n
         assert float((p.grad.cpu().double() - og.double()).norm()) <= 3e-4 * float(og.double().norm()) + 1e-6, n
+
+
+@pytest.mark.parametrize("tt", ["performer", "transformer"])
+def test_t2t_vit_14_at_224_matches_reference_fixture(tt):
+    """BASELINE config 4 at its own geometry: T2T-ViT-14 (D 384, depth 14, 6 heads, mlp_ratio 3) on a 224x224 image - the 3136-token
+    soft split, the 3136-token performer / transformer stage, the 784-token stage, the 14-block backbone - on the HIP path against
+    the fixture the reference's own T2T_ViT produced (tests/golden/t2t_224.npz), incl. every parameter-gradient norm."""
+    import vit_models
+    from d2s import synth
+    dev = torch.device("cuda:0")
+    g = cases.load_golden("t2t_224")
+    c = cases.T2T_224_CASE
+    m = vit_models.T2T_ViT(img_size=c["img_size"], tokens_type=tt, embed_dim=c["dim"], depth=c["depth"], num_heads=c["heads"],
+                           mlp_ratio=c["mlp_ratio"], num_classes=c["num_classes"], token_dim=64)
+    sd = cases.make_t2t_weights(tt, case=c)
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict({k: _t(v) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    x = _t(cases.make_t2t_images(c)).to(dev)
+    tok0 = m.tokens_to_token.soft_split0(x)
+    assert list(tok0.shape) == g[f"{tt}_unfold0_shape"].tolist()
+    np.testing.assert_array_equal(tok0[:, 1000:1004].cpu().numpy(), g[f"{tt}_unfold0_slice"])
+    a1 = m.tokens_to_token.attention1(tok0)
+    np.testing.assert_allclose(a1[:, ::392].detach().cpu().numpy(), g[f"{tt}_attention1_slice"], rtol=1e-4, atol=2e-5)
+    tm = m.tokens_to_token(x)
+    assert list(tm.shape) == g[f"{tt}_t2t_module_shape"].tolist()
+    np.testing.assert_allclose(tm[:, ::28, ::8].detach().cpu().numpy(), g[f"{tt}_t2t_module_slice"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(tm.detach().double().sum(dim=2).cpu().numpy(), g[f"{tt}_t2t_module_sum"], rtol=1e-4, atol=2e-3)
+    cls_feat, heads = m.forward_features(x)
+    logits = m(x)
+    assert len(heads) == int(g[f"{tt}_n_block_heads"])
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g[f"{tt}_logits"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(heads[-1][:, ::16].detach().cpu().numpy(), g[f"{tt}_block_head_last_slice"], rtol=1e-4, atol=3e-5)
+    gl = _t(synth.normal("t2t224/g", tuple(logits.shape), seed=9)).to(dev)
+    m.zero_grad()
+    (logits * gl).sum().backward()
+    params = dict(m.named_parameters())
+    for n, ref in zip([str(s) for s in g[f"{tt}_grad_names"]], g[f"{tt}_grad_norms"]):
+        if ref < 0:
+            assert params[n].grad is None, n
+            continue
+        np.testing.assert_allclose(float(params[n].grad.double().norm()), ref, rtol=2e-3, atol=1e-7, err_msg=n)
+
+
+def test_pruned_t2t_14_full_size_step_properties():
+    """BASELINE config 4 as bench.py --config c4 runs it (pruned T2T-ViT-14, keep 0.5 @ block 3, batch 64 at 224x224), where the oracle
+    is too slow to be the checker: the whole train step is bit-identical between two runs, kept / dropped ids are sorted, unique, in
+    range and partition the 196 tokens, the kept count is int(196 * 0.5), and the first 32 images give the same logits and ids alone
+    or inside the batch of 64 (batch independence: the property data parallelism rests on)."""
+    import vit_models
+    from d2s.engine import TrainStep
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    student = vit_models.t2t_vit_14_student([3], [0.5]).to(dev)
+    teacher = vit_models.t2t_vit_14_teacher().to(dev)
+    args = types.SimpleNamespace(keep_ratios=[0.5], mask_loss_type="kl_div", mixup=0.0, patch_score_threshold=None, step=0)
+    ts = TrainStep(student, teacher, args)
+    B = 64
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn((B, 3, 224, 224), device=dev, generator=g)
+    y = torch.randint(0, 1000, (B,), device=dev, generator=g)
+    runs = []
+    for _ in range(2):
+        student.train()
+        loss, info = ts.forward_losses(x, y)
+        ts.opt.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((float(loss), info["kept"][0].clone(), info["logits_s"].detach().clone(), ts.arena.grads.clone()))
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    assert torch.equal(runs[0][3], runs[1][3]), "gradients differ between two identical steps"
+    assert np.isfinite(runs[0][0])
+    kept, dropped = runs[0][1].cpu().numpy(), student.dropped_token_indices[0].cpu().numpy()
+    assert kept.shape == (B, 98) and dropped.shape == (B, 98)
+    assert (np.diff(kept, axis=1) > 0).all() and (np.diff(dropped, axis=1) > 0).all()
+    both = np.sort(np.concatenate([kept, dropped], axis=1), axis=1)
+    np.testing.assert_array_equal(both, np.tile(np.arange(196), (B, 1)))
+    with torch.no_grad():
+        _, half = ts.forward_losses(x[:32].contiguous(), y[:32].contiguous())
+    np.testing.assert_array_equal(half["kept"][0].cpu().numpy(), kept[:32])
+    np.testing.assert_allclose(half["logits_s"].cpu().numpy(), runs[0][2][:32].cpu().numpy(), rtol=1e-5, atol=1e-6)

@@ -403,6 +403,55 @@ def gen_t2t():
     print(f"[golden] t2t: {len(out)} arrays")
 
 
+def gen_t2t_224():
+    """BASELINE config 4 at its own geometry: the reference's T2T_ViT with the T2T-ViT-14 hyper-parameters (t2t_vit.py:182-199) on one
+    224x224 image, both token encoders (performer = T2t_vit_14, transformer = T2t_vit_t_14), eval mode: the 3136-token soft split and
+    first token encoder, the T2T module output, logits, the last block's normed output and every parameter-gradient norm of
+    sum(logits * g).  Slices + fp64 sums are stored where the tensors are large."""
+    import contextlib
+    import io
+    t2t = sys.modules["vit_models.t2t_vit"]
+    c = cases.T2T_224_CASE
+    out = {}
+    for tt in ("performer", "transformer"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = t2t.T2T_ViT(img_size=c["img_size"], tokens_type=tt, embed_dim=c["dim"], depth=c["depth"], num_heads=c["heads"],
+                            mlp_ratio=c["mlp_ratio"], num_classes=c["num_classes"], token_dim=64)
+        sd = cases.make_t2t_weights(tt, case=c)
+        own = m.state_dict()
+        assert list(own.keys()) == list(sd.keys())
+        m.load_state_dict({k: _t(v) for k, v in sd.items()})
+        m.eval()
+        x = _t(cases.make_t2t_images(c))
+        tok0 = m.tokens_to_token.soft_split0(x).transpose(1, 2)
+        a1 = m.tokens_to_token.attention1(tok0)
+        tm = m.tokens_to_token(x)
+        out[f"{tt}_unfold0_shape"] = np.array(tok0.shape)
+        out[f"{tt}_unfold0_slice"] = _np(tok0[:, 1000:1004, :])
+        out[f"{tt}_attention1_slice"] = _np(a1[:, ::392, :])
+        out[f"{tt}_attention1_sum"] = _np(a1.double().sum(dim=(0, 2)))[::49]
+        out[f"{tt}_t2t_module_shape"] = np.array(tm.shape)
+        out[f"{tt}_t2t_module_slice"] = _np(tm[:, ::28, ::8])
+        out[f"{tt}_t2t_module_sum"] = _np(tm.double().sum(dim=2))
+        cls_feat, block_heads = m.forward_features(x)
+        logits = m.head(cls_feat)
+        out[f"{tt}_logits"] = _np(logits)
+        out[f"{tt}_block_head_last_slice"] = _np(block_heads[-1][:, ::16])
+        out[f"{tt}_n_block_heads"] = np.array(len(block_heads))
+        g = _t(synth.normal("t2t224/g", tuple(logits.shape), seed=9))
+        m.zero_grad()
+        (logits * g).sum().backward()
+        names, norms = [], []
+        for n_, p_ in m.named_parameters():
+            names.append(n_)
+            norms.append(-1.0 if p_.grad is None else float(p_.grad.double().norm()))
+        out[f"{tt}_grad_names"] = np.array(names)
+        out[f"{tt}_grad_norms"] = np.array(norms)
+        print(f"[golden] t2t_224 {tt}: logits[:3] {logits[0, :3].tolist()}")
+    np.savez_compressed(os.path.join(OUT, "t2t_224.npz"), **out)
+    print(f"[golden] t2t_224: {len(out)} arrays")
+
+
 def gen_mask_loss_mse(losses):
     """MaskLoss with mask_loss_type='mse' (losses.py:61-73) at loss level: synthetic scores / teacher CLS-attention rows / kept ids in,
     loss and d loss / d scores out (two stages, so that the re-gather + renormalisation of the target is covered)."""
@@ -483,6 +532,7 @@ def main():
     gen_perturbed_topk(ptk)
     gen_micro_intermediates(dv)
     gen_t2t()
+    gen_t2t_224()
     gen_checkpoint_ingestion(dv)
     gen_param_groups(dv)
     gen_mask_loss_mse(losses)
