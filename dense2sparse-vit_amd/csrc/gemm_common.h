@@ -150,6 +150,88 @@ __device__ __forceinline__ void store_tile_out_lds(const GemmArgs& p, float* __r
     }
 }
 
+// The same LDS-staged 16-byte epilogue for accumulators of v_mfma_f32_16x16x4_f32 tiles: acc[mt][nt] is the 16x16 block (mt, nt) of the
+// wave's (MT*16) x (NT*16) sub-tile; register r of lane l holds row 4 * (l >> 4) + r, column l & 15 of it.  One 16-row slab (all NT column
+// blocks of one mt) is parked at a time; the read-back / global part is identical to the 32x32 form.
+template <int EPI, int MT, int NT>
+__device__ __forceinline__ void store_tile_out_lds16(const GemmArgs& p, float* __restrict__ Cb, const f32x4 (&acc)[MT][NT], int mrow0,
+                                                     int ncol0, int lane, float* __restrict__ stage_wave) {
+    constexpr int WN = NT * 16, PITCH = WN + 4, LPR = WN / 4, RPI = 64 / LPR, ITERS = 16 / RPI;
+    const int lq = lane >> 4, l15 = lane & 15;
+    const int rr = lane / LPR, c4 = (lane % LPR) * 4;
+    const int n = ncol0 + c4;
+    constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_ROWADD;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (HAS_BIAS && p.bias && n < p.N) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage_wave[(4 * lq + r) * PITCH + nt * 16 + l15] = acc[mt][nt][r];
+        // same-wave LDS accesses complete in order: no barrier needed for the wave-private buffer
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int row = it * RPI + rr;
+            const int m = mrow0 + mt * 16 + row;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage_wave + row * PITCH + c4);
+            if (m >= p.M || n >= p.N) continue;
+            long orow = m;
+            if (EPI == EPI_BIAS_ROWADD && p.remap_rows_per_img > 0)
+                orow = (long)m + (long)(m / p.remap_rows_per_img) * p.remap_skip + p.remap_skip;
+            float* cp = Cb + orow * p.ldc + n;
+            if (HAS_BIAS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += bias[j];
+            }
+            if (EPI == EPI_BIAS_RELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            if (EPI == EPI_BIAS_GELU) {
+                if (p.aux_out) *reinterpret_cast<f32x4*>(p.aux_out + (long)m * p.ldc + n) = v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            }
+            if (EPI == EPI_BIAS_RESID || EPI == EPI_MUL_GELU_GRAD || EPI == EPI_MUL_RELU_MASK) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + (long)m * p.ldaux + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (EPI == EPI_BIAS_RESID) v[j] += a[j];
+                    if (EPI == EPI_MUL_GELU_GRAD) v[j] *= gelu_erf_grad(a[j]);
+                    if (EPI == EPI_MUL_RELU_MASK) v[j] = a[j] > 0.f ? v[j] : 0.f;
+                }
+            }
+            if (EPI == EPI_BIAS_ROWADD) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + (long)(m % p.aux_rows) * p.ldaux + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += a[j];
+            }
+            if (EPI == EPI_ACCUM) {
+                const f32x4 o = *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += o[j];
+            }
+            *reinterpret_cast<f32x4*>(cp) = v;
+        }
+    }
+}
+template <int MT, int NT>
+__device__ __forceinline__ void store_tile_dispatch_lds16(int epi, const GemmArgs& p, float* Cb, const f32x4 (&acc)[MT][NT], int mr, int nc,
+                                                          int lane, float* stage) {
+    switch (epi) {
+        case EPI_BIAS: store_tile_out_lds16<EPI_BIAS, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_BIAS_RELU: store_tile_out_lds16<EPI_BIAS_RELU, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_BIAS_GELU: store_tile_out_lds16<EPI_BIAS_GELU, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_BIAS_RESID: store_tile_out_lds16<EPI_BIAS_RESID, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_MUL_GELU_GRAD: store_tile_out_lds16<EPI_MUL_GELU_GRAD, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_MUL_RELU_MASK: store_tile_out_lds16<EPI_MUL_RELU_MASK, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_BIAS_ROWADD: store_tile_out_lds16<EPI_BIAS_ROWADD, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_ACCUM: store_tile_out_lds16<EPI_ACCUM, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        default: store_tile_out_lds16<EPI_NONE, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+    }
+}
+
 // resolve the (wave-uniform) epilogue kind once; each kind has its own straight-line store loop
 template <int MT, int NT>
 __device__ __forceinline__ void store_tile_dispatch_lds(int epi, const GemmArgs& p, float* Cb, const f32x16 (&acc)[MT][NT], int mr, int nc,

@@ -97,7 +97,8 @@ __device__ __forceinline__ void load_tile_fast(const float* __restrict__ P, long
 
 template <int LAY, int BR>
 __device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const f32x4 (&r)[BR / 64]) {
-    // S: [BK][BR] floats, element (k,row) at k*BR + (row ^ (((k>>2)&3)<<3))
+    // S: [BK][BR] floats, element (k,row) at k*BR + (row ^ (((k>>2)&3)<<3) ^ ((k&1)<<4)).  The (k&1)<<4 term makes the fragment reads of
+    // the 16x16x4 form (lanes l and l+16 of a half-wave read rows k and k+1 of the same 16 columns) conflict-free as well
 #pragma unroll
     for (int i = 0; i < BR / 64; ++i) {
         const int f = tid + i * 256;
@@ -105,10 +106,10 @@ __device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const
             const int row = f >> 2, kq = f & 3;
             const int col = row ^ (kq << 3);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) S[(kq * 4 + j) * BR + col] = r[i][j];
+            for (int j = 0; j < 4; ++j) S[(kq * 4 + j) * BR + (col ^ ((j & 1) << 4))] = r[i][j];
         } else {
             const int k = f / (BR / 4), row = (f % (BR / 4)) * 4;
-            const int col = row ^ (((k >> 2) & 3) << 3);
+            const int col = row ^ (((k >> 2) & 3) << 3) ^ ((k & 1) << 4);
             *reinterpret_cast<f32x4*>(&S[k * BR + col]) = r[i];
         }
     }
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 1) void gemm_f3
         float a[2][MT], b[2][NT];
         auto read_frags = [&](int sp, float (&af)[MT], float (&bf)[NT]) {
             const int k = 2 * sp + half;
-            const int sw = ((k >> 2) & 3) << 3;
+            const int sw = (((k >> 2) & 3) << 3) ^ ((k & 1) << 4);
 #pragma unroll
             for (int i = 0; i < MT; ++i) af[i] = Ac[k * BM + ((wm * WM + i * 32 + l31) ^ sw)];
 #pragma unroll
@@ -292,6 +293,131 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 1) void gemm_f3
         case EPI_ACCUM: store_tile_out<EPI_ACCUM, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
         default: store_tile_out<EPI_NONE, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
     }
+}
+
+// The same GEMM on v_mfma_f32_16x16x4_f32 (same FLOP per cycle as 32x32x2 - 64 per clock and SIMD - and the same exact fp32 fma chain,
+// k-ordered): a wave's 64x64 (32x32) sub-tile is 4x4 (2x2) accumulator blocks of 16x16.  Lane l feeds A[row = l & 15][k = l >> 4] and
+// B[k = l >> 4][col = l & 15], so one fragment register covers FOUR k values: per 16-deep K-step the wave issues the same 32 ds_read_b32 as
+// the 32x32x2 form but 64 MFMAs of 32 cycles instead of 32 of 64.  Used for the guard-free (FAST) shapes with the 16-byte epilogue; whether
+// it is the default is a measured choice (the chip may hold a different clock on the two shapes, MI355X_MICROARCH.md 'DVFS give-back' 7).
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+template <int ALAY, int BLAY, int BM, int BN>
+__global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 1) void gemm_f32_kernel16(GemmArgs p) {
+    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16;   // 2x2 waves, each MT x NT MFMA blocks of 16x16
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+    float* As = smem;
+    float* Bs = smem + 2 * BK * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane >> 4, l15 = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / nbn, bn = bid % nbn;
+    const int row0 = bm * BM, col0 = bn * BN;
+    const int kbeg = blockIdx.z * p.k_per_slice;
+    const int kend = min(p.K, kbeg + p.k_per_slice);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bool do_colsum = (ALAY == 1) && p.colsum != nullptr && bn == 0;
+    f32x4 csum[BM / 64];
+#pragma unroll
+    for (int i = 0; i < BM / 64; ++i) csum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ra[BM / 64], rb[BN / 64];
+    long offa[BM / 64], offb[BN / 64];
+    tile_offsets<ALAY, BM>(p.lda, row0, p.M, tid, offa);
+    tile_offsets<BLAY, BN>(p.ldb, col0, p.N, tid, offb);
+    if (nk > 0) {
+        load_tile_fast<ALAY, BM>(p.A, p.lda, kbeg, offa, ra);
+        load_tile_fast<BLAY, BN>(p.B, p.ldb, kbeg, offb, rb);
+        if (ALAY == 1 && do_colsum) {
+#pragma unroll
+            for (int i = 0; i < BM / 64; ++i) csum[i] += ra[i];
+        }
+        store_tile<ALAY, BM>(As, tid, ra);
+        store_tile<BLAY, BN>(Bs, tid, rb);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const int kn = kbeg + min(kt + 1, nk - 1) * BK;       // branch-free prefetch (the last trip re-reads the last slab and discards it)
+        load_tile_fast<ALAY, BM>(p.A, p.lda, kn, offa, ra);
+        load_tile_fast<BLAY, BN>(p.B, p.ldb, kn, offb, rb);
+        const float* Ac = As + cur * BK * BM;
+        const float* Bc = Bs + cur * BK * BN;
+        float a[2][MT], b[2][NT];
+        auto read_frags = [&](int q, float (&af)[MT], float (&bf)[NT]) {
+            const int k = 4 * q + lq;
+            const int sw = ((q & 3) << 3) ^ ((lq & 1) << 4);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = Ac[k * BM + ((wm * WM + i * 16 + l15) ^ sw)];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = Bc[k * BN + ((wn * WN + j * 16 + l15) ^ sw)];
+        };
+        read_frags(0, a[0], b[0]);
+#pragma unroll
+        for (int q = 0; q < BK / 4; ++q) {
+            if (q + 1 < BK / 4) read_frags(q + 1, a[(q + 1) & 1], b[(q + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(a[q & 1][i], b[q & 1][j], acc[i][j]);
+        }
+        {   // issue order of the K-step: fragment reads of quad q + 1 ahead of the MFMAs of quad q, global loads spread over the quads
+            constexpr int NL = BM / 64 + BN / 64, NQ = BK / 4;
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q + 1 < NQ) __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT / 2, 0);
+                if (q < NL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - MT * NT / 2, 0);
+            }
+        }
+        if (kt + 1 < nk) {
+            store_tile<ALAY, BM>(As + (cur ^ 1) * BK * BM, tid, ra);
+            store_tile<BLAY, BN>(Bs + (cur ^ 1) * BK * BN, tid, rb);
+            if (ALAY == 1 && do_colsum) {
+#pragma unroll
+                for (int i = 0; i < BM / 64; ++i) csum[i] += ra[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    if (ALAY == 1 && do_colsum) {
+        constexpr int CH = BM / 4, G = 256 / CH;
+        f32x4 t = csum[0];
+#pragma unroll
+        for (int i = 1; i < BM / 64; ++i) t += csum[i];
+        *reinterpret_cast<f32x4*>(&smem[(tid / CH) * BM + (tid % CH) * 4]) = t;
+        __syncthreads();
+        if (tid < BM && row0 + tid < p.M) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) s += smem[g * BM + tid];
+            float* o = p.colsum + (long)blockIdx.z * p.M + row0 + tid;
+            *o = (gridDim.z == 1 && p.colsum_accumulate) ? *o + s : s;
+        }
+        __syncthreads();
+    }
+    float* Cb = p.C + (long)blockIdx.z * p.slab_stride;
+    const int epi = (gridDim.z > 1) ? (int)EPI_NONE : p.epi;
+    static_assert(4 * 16 * (WN + 4) <= 2 * BK * (BM + BN), "epilogue staging must fit the operand buffers");
+    store_tile_dispatch_lds16<MT, NT>(epi, p, Cb, acc, row0 + wm * WM, col0 + wn * WN, lane, smem + wave * 16 * (WN + 4));
 }
 
 // Deterministic split-K combine: C (+)= sum over slabs in slab order.
@@ -446,17 +572,43 @@ inline Tile pick_tile(int M, int N) {
     return best;
 }
 
+// Residency cap: a bare loop of f32 MFMAs issues at 0.99 of the pipe's rate with one or two waves per SIMD and at 0.80 with four
+// (tools/micro/mfma_shape_f32.hip, profiles/r02_mfma_residency.txt), so more co-resident workgroups than the latency hiding needs cost
+// matrix throughput.  Unused dynamic LDS is the knob: asking for 160 KB / k - static bytes per workgroup lets a CU hold exactly k.
+inline unsigned residency_pad(int bm, int bn) {
+    static const int cap = [] { const char* e = getenv("D2S_GEMM_WG_PER_CU"); return e ? atoi(e) : 0; }();
+    if (cap <= 0) return 0;
+    const int static_bytes = 2 * BK * (bm + bn) * (int)sizeof(float) + 64;
+    const int want = (160 * 1024) / cap - static_bytes - 512;
+    return want > 0 ? (unsigned)(want & ~255) : 0u;
+}
 template <int ALAY, int BLAY, bool FAST>
 inline void launch_gemm_f(const Tile& t, dim3 grid, hipStream_t stream, const GemmArgs& p) {
     dim3 block(256);
-    if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 128, 128, FAST>), grid, block, 0, stream, p);
-    else if (t.bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 128, 64, FAST>), grid, block, 0, stream, p);
-    else if (t.bn == 128) hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 64, 128, FAST>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 64, 64, FAST>), grid, block, 0, stream, p);
+    const unsigned pad = residency_pad(t.bm, t.bn);
+    if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 128, 128, FAST>), grid, block, pad, stream, p);
+    else if (t.bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 128, 64, FAST>), grid, block, pad, stream, p);
+    else if (t.bn == 128) hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 64, 128, FAST>), grid, block, pad, stream, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<ALAY, BLAY, 64, 64, FAST>), grid, block, pad, stream, p);
+}
+template <int ALAY, int BLAY>
+inline void launch_gemm16(const Tile& t, dim3 grid, hipStream_t stream, const GemmArgs& p) {
+    dim3 block(256);
+    const unsigned pad = residency_pad(t.bm, t.bn);
+    if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((gemm_f32_kernel16<ALAY, BLAY, 128, 128>), grid, block, pad, stream, p);
+    else if (t.bm == 128) hipLaunchKernelGGL((gemm_f32_kernel16<ALAY, BLAY, 128, 64>), grid, block, pad, stream, p);
+    else if (t.bn == 128) hipLaunchKernelGGL((gemm_f32_kernel16<ALAY, BLAY, 64, 128>), grid, block, pad, stream, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel16<ALAY, BLAY, 64, 64>), grid, block, pad, stream, p);
+}
+// D2S_GEMM_MFMA16: 1 = run the guard-free shapes on the 16x16x4 form, 0 = always the 32x32x2 form
+inline bool use_mfma16() {
+    static const int on = [] { const char* e = getenv("D2S_GEMM_MFMA16"); return e ? atoi(e) : 0; }();
+    return on != 0;
 }
 template <int ALAY, int BLAY>
 inline void launch_gemm(const Tile& t, dim3 grid, hipStream_t stream, const GemmArgs& p, bool fast) {
-    if (fast) launch_gemm_f<ALAY, BLAY, true>(t, grid, stream, p);
+    if (fast && p.vec_epilogue && use_mfma16()) launch_gemm16<ALAY, BLAY>(t, grid, stream, p);
+    else if (fast) launch_gemm_f<ALAY, BLAY, true>(t, grid, stream, p);
     else launch_gemm_f<ALAY, BLAY, false>(t, grid, stream, p);
 }
 

@@ -105,11 +105,12 @@ def embed_tokens(sd, x, cfg):
 def softmax_with_policy(attn, policy, eps=1e-6):
     """Attention.softmax_with_policy, vit_models/dynamic_vit.py:195-214."""
     B, N, _ = policy.shape
-    pol = policy.reshape(B, 1, 1, N)
-    eye = torch.eye(N, dtype=pol.dtype).view(1, 1, N, N)
+    work = torch.float64 if attn.dtype == torch.float64 else torch.float32     # the reference casts to float32 (:210); an fp64 run of
+    pol = policy.reshape(B, 1, 1, N).to(work)                                    # the oracle (gradient-accuracy checks) stays in fp64
+    eye = torch.eye(N, dtype=work).view(1, 1, N, N)
     pol = pol + (1.0 - pol) * eye
     attn = attn - attn.max(dim=-1, keepdim=True)[0]
-    attn = attn.to(torch.float32).exp() * pol.to(torch.float32)
+    attn = attn.to(work).exp() * pol
     return (attn + eps / N) / (attn.sum(dim=-1, keepdim=True) + eps)
 
 
@@ -277,6 +278,18 @@ def select_threshold(keep_probs, threshold):
     return mask.float(), th.sum(dim=1)
 
 
+def select_threshold_stable(keep_probs, threshold):
+    """The same selection with the tie rule spelled out: equal probabilities are taken lowest index first (a stable ascending sort),
+    i.e. of two tied tokens that straddle the threshold the one with the lower index is the one dropped.  torch.sort without
+    stable=True leaves that order to the sort implementation (on this build pairs of equal values come out in either order), so the
+    reference itself only defines the NUMBER of kept tokens and the multiset of their probabilities on such rows; this is the rule the
+    HIP kernel implements."""
+    val, idx = torch.sort(keep_probs.detach().clone(), stable=True)
+    th = torch.cumsum(val, dim=-1) > threshold
+    mask = torch.scatter(torch.zeros_like(th), 1, idx, th)
+    return mask.float(), th.sum(dim=1)
+
+
 def student_forward_threshold_train(sd, x, cfg, threshold):
     """VisionTransformerDiffPruning.forward in training mode with patch_score_threshold set (:826-894, :981-983, :993-1011): no token
     is removed; a stage's mask becomes the key policy of that block and every later block (softmax_with_policy, :195-214), blocks
@@ -291,6 +304,7 @@ def student_forward_threshold_train(sd, x, cfg, threshold):
         if i in cfg["pruning_loc"]:
             scores, probs = predictor(sd, stage, x[:, 1:], cfg)
             mask, _ = select_threshold(probs, threshold)
+            mask = mask.to(x.dtype)
             policy = torch.cat((torch.ones(B, 1, dtype=x.dtype), mask), dim=1).unsqueeze(-1)
             pred_logits.append(scores)
             masks.append(mask)

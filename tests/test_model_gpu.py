@@ -204,6 +204,7 @@ def test_optimizer_warmup_to_full_transition():
     ts = TrainStep(student, teacher, make_args(cfg), **hp)
     st = O.TrainState({k: _t(v) for k, v in sd_s.items()}, {k: _t(v) for k, v in sd_t.items()}, cfg, **hp)
     nsteps = 0
+    gate_noise = False
     for epoch in (0, 1):
         ts.set_epoch(epoch)
         st.set_epoch(epoch)
@@ -212,6 +213,10 @@ def test_optimizer_warmup_to_full_transition():
             oinfo = st.step(x, y)
             nsteps += 1
             np.testing.assert_allclose(float(info["loss"]), float(oinfo["loss"]), rtol=5e-5, err_msg=f"epoch {epoch}")
+            # a predictor ReLU whose pre-activation sits within fp32 rounding of zero is gated by rounding noise (see
+            # test_train_step_parity): the predictor gradients below that layer then differ by ~1e-3 between ANY two fp32
+            # implementations, and Adam carries that into the predictor's parameters.  The backbone is not downstream of those gates.
+            gate_noise = gate_noise or min(oinfo["aux"]["relu_margins"]) < 5e-6
         if epoch == 0:
             for n, p in student.named_parameters():
                 if "predictor" not in n:
@@ -226,14 +231,24 @@ def test_optimizer_warmup_to_full_transition():
     for n, p in student.named_parameters():
         ref = st.sd_s[n].detach().numpy()
         got = p.detach().cpu().numpy()
-        bad = ~np.isclose(got, ref, rtol=2e-4, atol=2e-6)
         og = st.sd_s[n].grad
-        if not (og is not None and float(og.double().norm()) < 1e-6):
-            assert bad.mean() <= 2e-4, (n, float(bad.mean()))
-        # a wrong bias correction (global step 3 instead of per-tensor step 1) makes the first backbone update 0.1/ (1-0.9^3) ... i.e.
-        # several times too small or large: every element would miss by O(lr), which the rtol check above catches; this bounds the rest
+        if og is not None and float(og.double().norm()) < 1e-6:
+            continue                                     # exactly-zero gradient in exact arithmetic: Adam turns rounding noise into +-lr
+        if "predictor" in n:
+            bad = ~np.isclose(got, ref, rtol=2e-4, atol=2e-6)
+            assert bad.mean() <= (3e-2 if gate_noise else 2e-4), (n, float(bad.mean()), gate_noise)
+        else:
+            # the backbone's FIRST updates: with the global step (3, 4) in place of the per-tensor step (1, 2) the bias corrections
+            # would make them 0.27 / 0.51 of the reference's, i.e. every element off by more than 0.4 * backbone_lr per step; measured in
+            # units of that lr, the mean |difference| must be far below it
+            diff = np.abs(got - ref)
+            moved = np.abs(ref - sd_s[n])
+            bb_lr = min(hp["lr"] * 0.01, hp["lr"])
+            assert float(moved.mean()) > 0.2 * bb_lr, (n, "the reference did not move this tensor?")
+            assert float(diff.mean()) < 0.02 * bb_lr, (n, float(diff.mean()) / bb_lr)
         worst = max(worst, float(np.abs(got - ref).max()))
     assert worst <= 2 * nsteps * hp["lr"] * 1.01
+    print(f"[warm-up -> full transition] relu gate at noise level during the run: {gate_noise}")
 
 
 def test_normal_noise_stream():

@@ -191,6 +191,12 @@ def test_oracle_threshold_selection_matches_reference_lines():
             mask, counts = O.select_threshold(p, th)
             np.testing.assert_array_equal(mask.numpy() > 0, g[f"mask_{N}_{th}"])
             assert counts.tolist() == g[f"mask_{N}_{th}"].sum(axis=1).tolist()
+            # the stable statement of the rule (what the HIP kernel implements) defines the same counts and the same kept values;
+            # it can only differ in WHICH of several exactly tied tokens is kept
+            smask, scounts = O.select_threshold_stable(p, th)
+            assert scounts.tolist() == counts.tolist()
+            for r in range(p.shape[0]):
+                np.testing.assert_array_equal(np.sort(p[r][smask[r] > 0].numpy()), np.sort(p[r][mask[r] > 0].numpy()))
 
 
 @pytest.mark.parametrize("name", list(cases.THRESHOLD_CASES))

@@ -57,6 +57,8 @@ __global__ __launch_bounds__(256) void loop_kernel(const float* __restrict__ in,
 }
 
 int main() {
+    // Residency sweep: dynamic LDS per workgroup caps the workgroups a CU can hold (160 KB per CU): 96 KB -> 1 (one wave per SIMD),
+    // 64 KB -> 2, 48 KB -> 3, 36 KB -> 4.  The grid always supplies 4 workgroups per CU of work.
     const int blocks = 256 * 4, iters = 20000;
     float *in, *out; unsigned long long* clk;
     hipMalloc(&in, (1 << 20) * 4); hipMalloc(&out, blocks * 256 * 4); hipMalloc(&clk, blocks * 16);
@@ -64,19 +66,25 @@ int main() {
     for (auto& v : h) v = (rand() / (float)RAND_MAX - 0.5f) * 2e-3f;
     hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     std::vector<unsigned long long> hc(blocks * 2);
-    for (int shape : {32, 16, 32, 16}) {
-        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        for (int rep = 0; rep < 3; ++rep) {
-            hipEventRecord(e0);
-            if (shape == 32) hipLaunchKernelGGL(loop_kernel<32>, dim3(blocks), dim3(256), 0, 0, in, out, iters, clk);
-            else hipLaunchKernelGGL(loop_kernel<16>, dim3(blocks), dim3(256), 0, 0, in, out, iters, clk);
-            hipEventRecord(e1); hipEventSynchronize(e1);
+    hipFuncSetAttribute((const void*)loop_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)loop_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int lds_kb : {96, 64, 48, 36}) {
+        for (int shape : {32, 16, 32, 16}) {
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEventRecord(e0);
+                if (shape == 32) hipLaunchKernelGGL(loop_kernel<32>, dim3(blocks), dim3(256), lds_kb * 1024, 0, in, out, iters, clk);
+                else hipLaunchKernelGGL(loop_kernel<16>, dim3(blocks), dim3(256), lds_kb * 1024, 0, in, out, iters, clk);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+            }
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpy(hc.data(), clk, hc.size() * 8, hipMemcpyDeviceToHost);
+            double mhz = 0; for (int i = 0; i < blocks; ++i) mhz += 100.0 * hc[2 * i] / hc[2 * i + 1]; mhz /= blocks;
+            const double flop = (double)blocks * 4 /*waves*/ * iters * 16 * 4096.0;   // per trip: 16 x 32x32x2 (4096 FLOP) == 32 x 16x16x4 (2048 FLOP)
+            const double peak_at_clock = 256.0 * 4 * 64 * mhz * 1e6 / 1e12;
+            printf("workgroups/CU %d (LDS %3d KB)  shape %2dx%-2d: %8.2f ms  %7.1f TFLOP/s  in-kernel clock %5.0f MHz  -> %.3f of the issue peak at that clock\n",
+                   lds_kb == 96 ? 1 : lds_kb == 64 ? 2 : lds_kb == 48 ? 3 : 4, lds_kb, shape, shape, ms, flop / ms / 1e9, mhz, flop / ms / 1e9 / peak_at_clock);
         }
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        hipMemcpy(hc.data(), clk, hc.size() * 8, hipMemcpyDeviceToHost);
-        double mhz = 0; for (int i = 0; i < blocks; ++i) mhz += 100.0 * hc[2 * i] / hc[2 * i + 1]; mhz /= blocks;
-        const double flop = (double)blocks * 4 /*waves*/ * iters * 16 * 4096.0;   // per trip: 16 x 32x32x2 (4096 FLOP) == 32 x 16x16x4 (2048 FLOP)
-        printf("shape %2dx%-2d: %8.2f ms  %7.1f TFLOP/s  in-kernel clock %5.0f MHz\n", shape, shape, ms, flop / ms / 1e9, mhz);
     }
     return 0;
 }
