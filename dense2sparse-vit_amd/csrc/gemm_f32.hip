@@ -420,6 +420,131 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 1) void gemm_f3
     store_tile_dispatch_lds16<MT, NT>(epi, p, Cb, acc, row0 + wm * WM, col0 + wn * WN, lane, smem + wave * 16 * (WN + 4));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// "rk" form for k-contiguous operands (ALAY 0: activations / gradients [M][K]; BLAY 0: weights [N][K]): the LDS image of such an
+// operand is [row][16 k] - exactly as it sits in memory - so a global float4 goes to LDS with ONE ds_write_b128 (the [k][row] image
+// needs four transposing ds_write_b32) and a lane fetches its 8 k-values of a K-step with TWO ds_read_b128 (instead of eight
+// ds_read_b32).  For that the k order inside a K-step is permuted: MFMA step s of a 16-deep K-step multiplies k = s (lanes 0-31) and
+// k = 8 + s (lanes 32-63); the same permutation is applied to both operands, so every product a_k * b_k is still formed exactly once -
+// only the order of the fp32 accumulation chain changes (still deterministic).  Per wave and K-step of the 128x128 NT tile: 8
+// ds_read_b128 + 4 ds_write_b128 where the [k][row] image issues 32 ds_read_b32 + 16 ds_write_b32, for the same 32 MFMAs.
+// 16-byte chunks of a row are XOR-swizzled by (row >> 2) & 3: conflict-free ds_write_b128 (4 rows x 4 chunks per 16 lanes) and
+// ds_read_b128 (16 consecutive rows, one chunk).  A k-major B operand (NN layout) keeps the [k][row] image and is read with k = 8h + s.
+template <int BR>
+__device__ __forceinline__ void store_tile_rk(float* __restrict__ S, int tid, const f32x4 (&r)[BR / 64]) {
+#pragma unroll
+    for (int i = 0; i < BR / 64; ++i) {
+        const int f = tid + i * 256;
+        const int row = f >> 2, kq = f & 3;
+        *reinterpret_cast<f32x4*>(&S[row * BK + ((kq ^ ((row >> 2) & 3)) << 2)]) = r[i];
+    }
+}
+
+template <int BLAY, int BM, int BN>
+__global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 1) void gemm_f32_rk_kernel(GemmArgs p) {
+    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+    float* As = smem;                 // [2][BM][BK]  (rk image)
+    float* Bs = smem + 2 * BK * BM;   // [2][BN][BK]  (rk image, BLAY 0)  or  [2][BK][BN]  ([k][row] image, BLAY 1)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / nbn, bn = bid % nbn;
+    const int row0 = bm * BM, col0 = bn * BN;
+    const int kbeg = blockIdx.z * p.k_per_slice;
+    const int kend = min(p.K, kbeg + p.k_per_slice);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[BM / 64], rb[BN / 64];
+    long offa[BM / 64], offb[BN / 64];
+    tile_offsets<0, BM>(p.lda, row0, p.M, tid, offa);
+    tile_offsets<BLAY, BN>(p.ldb, col0, p.N, tid, offb);
+    if (nk > 0) {
+        load_tile_fast<0, BM>(p.A, p.lda, kbeg, offa, ra);
+        load_tile_fast<BLAY, BN>(p.B, p.ldb, kbeg, offb, rb);
+        store_tile_rk<BM>(As, tid, ra);
+        if (BLAY == 0) store_tile_rk<BN>(Bs, tid, rb);
+        else store_tile<1, BN>(Bs, tid, rb);
+    }
+    __syncthreads();
+
+    // per-lane fragment addresses inside a buffer (floats): row * BK + ((chunk ^ swz(row)) << 2), chunk = 2 * half + c
+    int a_off[MT][2], b_off[NT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row = wm * WM + i * 32 + l31;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) a_off[i][c] = row * BK + (((2 * half + c) ^ ((row >> 2) & 3)) << 2);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int row = wn * WN + j * 32 + l31;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) b_off[j][c] = row * BK + (((2 * half + c) ^ ((row >> 2) & 3)) << 2);
+    }
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const int kn = kbeg + min(kt + 1, nk - 1) * BK;
+        load_tile_fast<0, BM>(p.A, p.lda, kn, offa, ra);
+        load_tile_fast<BLAY, BN>(p.B, p.ldb, kn, offb, rb);
+        const float* Ac = As + cur * BK * BM;
+        const float* Bc = Bs + cur * BK * BN;
+        f32x4 av[MT][2], bv[NT][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i][c] = *reinterpret_cast<const f32x4*>(Ac + a_off[i][c]);
+            if (BLAY == 0) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bv[j][c] = *reinterpret_cast<const f32x4*>(Bc + b_off[j][c]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float bs[NT];
+            if (BLAY == 0) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bs[j] = bv[j][s >> 2][s & 3];
+            } else {      // [k][row] image, k = 8 * half + s
+                const int k = 8 * half + s;
+                const int sw = (((k >> 2) & 3) << 3) ^ ((k & 1) << 4);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bs[j] = Bc[k * BN + ((wn * WN + j * 32 + l31) ^ sw)];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(av[i][s >> 2][s & 3], bs[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) {
+            store_tile_rk<BM>(As + (cur ^ 1) * BK * BM, tid, ra);
+            if (BLAY == 0) store_tile_rk<BN>(Bs + (cur ^ 1) * BK * BN, tid, rb);
+            else store_tile<1, BN>(Bs + (cur ^ 1) * BK * BN, tid, rb);
+        }
+        __syncthreads();
+    }
+
+    float* Cb = p.C + (long)blockIdx.z * p.slab_stride;
+    const int epi = (gridDim.z > 1) ? (int)EPI_NONE : p.epi;
+    store_tile_dispatch_lds<MT, NT>(epi, p, Cb, acc, row0 + wm * WM, col0 + wn * WN, lane, smem + wave * epi_stage_floats(NT));
+}
+
 // Deterministic split-K combine: C (+)= sum over slabs in slab order.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C,
                                                             long ldc, int M, int N, int slabs, long slab_stride,
@@ -600,6 +725,22 @@ inline void launch_gemm16(const Tile& t, dim3 grid, hipStream_t stream, const Ge
     else if (t.bn == 128) hipLaunchKernelGGL((gemm_f32_kernel16<ALAY, BLAY, 64, 128>), grid, block, pad, stream, p);
     else hipLaunchKernelGGL((gemm_f32_kernel16<ALAY, BLAY, 64, 64>), grid, block, pad, stream, p);
 }
+template <int BLAY>
+inline void launch_gemm_rk(const Tile& t, dim3 grid, hipStream_t stream, const GemmArgs& p) {
+    dim3 block(256);
+    const unsigned pad = residency_pad(t.bm, t.bn);
+    if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((gemm_f32_rk_kernel<BLAY, 128, 128>), grid, block, pad, stream, p);
+    else if (t.bm == 128) hipLaunchKernelGGL((gemm_f32_rk_kernel<BLAY, 128, 64>), grid, block, pad, stream, p);
+    else if (t.bn == 128) hipLaunchKernelGGL((gemm_f32_rk_kernel<BLAY, 64, 128>), grid, block, pad, stream, p);
+    else hipLaunchKernelGGL((gemm_f32_rk_kernel<BLAY, 64, 64>), grid, block, pad, stream, p);
+}
+// D2S_GEMM_RK [1]: k-contiguous A operands (NT / NN layouts, guard-free shapes) use the [row][k] LDS image (ds_*_b128); 0 = the [k][row]
+// image everywhere.  Measured on the model's shapes at B = 128 (tools/gemm_bench.py, profiles/r02_c_gemm_rk_vs_krow.txt): +20...30 % on
+// the N = 384 outputs and the K = 1536 / 1152 reductions, +4...7 % on the wide outputs, within +-2 % on the n = 99 input-gradient shapes
+inline bool use_rk() {
+    static const int on = [] { const char* e = getenv("D2S_GEMM_RK"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
 // D2S_GEMM_MFMA16: 1 = run the guard-free shapes on the 16x16x4 form, 0 = always the 32x32x2 form
 inline bool use_mfma16() {
     static const int on = [] { const char* e = getenv("D2S_GEMM_MFMA16"); return e ? atoi(e) : 0; }();
@@ -607,7 +748,8 @@ inline bool use_mfma16() {
 }
 template <int ALAY, int BLAY>
 inline void launch_gemm(const Tile& t, dim3 grid, hipStream_t stream, const GemmArgs& p, bool fast) {
-    if (fast && p.vec_epilogue && use_mfma16()) launch_gemm16<ALAY, BLAY>(t, grid, stream, p);
+    if (fast && p.vec_epilogue && ALAY == 0 && use_rk()) launch_gemm_rk<BLAY>(t, grid, stream, p);
+    else if (fast && p.vec_epilogue && use_mfma16()) launch_gemm16<ALAY, BLAY>(t, grid, stream, p);
     else if (fast) launch_gemm_f<ALAY, BLAY, true>(t, grid, stream, p);
     else launch_gemm_f<ALAY, BLAY, false>(t, grid, stream, p);
 }

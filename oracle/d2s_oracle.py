@@ -290,19 +290,21 @@ def select_threshold_stable(keep_probs, threshold):
     return mask.float(), th.sum(dim=1)
 
 
-def student_forward_threshold_train(sd, x, cfg, threshold):
+def student_forward_threshold_train(sd, x, cfg, threshold, relu_margins=None):
     """VisionTransformerDiffPruning.forward in training mode with patch_score_threshold set (:826-894, :981-983, :993-1011): no token
     is removed; a stage's mask becomes the key policy of that block and every later block (softmax_with_policy, :195-214), blocks
     before the first stage use the all-ones policy, a later stage replaces the mask.  Returns (logits, features [B,N,D],
-    [pred_logits per stage], [mask [B,N] per stage]) - the reference returns the LAST stage's pred_logits / mask only (:1011)."""
+    [pred_logits per stage], [mask [B,N] per stage]) - the reference returns the LAST stage's pred_logits / mask only (:1011).
+    relu_margins (optional list): receives min |pre-activation| of every predictor ReLU (see student_forward)."""
     x = embed_tokens(sd, x, cfg)
     B, n, _ = x.shape
     policy = torch.ones(B, n, 1, dtype=x.dtype)
     pred_logits, masks = [], []
     stage = 0
+    margins = relu_margins if relu_margins is not None else []
     for i in range(cfg["depth"]):
         if i in cfg["pruning_loc"]:
-            scores, probs = predictor(sd, stage, x[:, 1:], cfg)
+            scores, probs = predictor(sd, stage, x[:, 1:], cfg, margins)
             mask, _ = select_threshold(probs, threshold)
             mask = mask.to(x.dtype)
             policy = torch.cat((torch.ones(B, 1, dtype=x.dtype), mask), dim=1).unsqueeze(-1)

@@ -234,6 +234,9 @@ def test_optimizer_warmup_to_full_transition():
         og = st.sd_s[n].grad
         if og is not None and float(og.double().norm()) < 1e-6:
             continue                                     # exactly-zero gradient in exact arithmetic: Adam turns rounding noise into +-lr
+        if "cls_token" in n or "pos_embed" in n:      # in no parameter group (utils.py:79-80): never updated on either side
+            np.testing.assert_array_equal(got, sd_s[n], err_msg=n)
+            continue
         if "predictor" in n:
             bad = ~np.isclose(got, ref, rtol=2e-4, atol=2e-6)
             assert bad.mean() <= (3e-2 if gate_noise else 2e-4), (n, float(bad.mean()), gate_noise)

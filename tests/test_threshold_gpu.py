@@ -137,13 +137,19 @@ def test_threshold_training_forward_matches_reference(name):
     # (a) against the reference's fixture: L2 norm and leading elements; (b) the full tensors against an fp64 run of the oracle: the HIP
     # fp32 gradient must be as close to the exact one as the CPU fp32 oracle is (within 4x, floor 2e-4) - both are fp32 evaluations
     # in different summation orders, through up to 12 layers of policy attention
+    margins = []
+
     def probe(sd, dtype):
-        lo, fe, pl, _ = O.student_forward_threshold_train(sd, _t(cases.make_images(case)).to(dtype), case["cfg"], case["threshold"])
+        lo, fe, pl, _ = O.student_forward_threshold_train(sd, _t(cases.make_images(case)).to(dtype), case["cfg"], case["threshold"], margins)
         ((lo * g1.cpu().to(dtype)).sum() + (fe * g2.cpu().to(dtype)).sum() / fe.shape[1] + (pl[-1] * g3.cpu().to(dtype)).sum()).backward()
     sd32 = {k: _t(v).requires_grad_(True) for k, v in sd_s.items()}
     sd64 = {k: _t(v).double().requires_grad_(True) for k, v in sd_s.items()}
     probe(sd32, torch.float32)
     probe(sd64, torch.float64)
+    # a predictor ReLU whose pre-activation is within fp32 rounding of zero is gated by rounding noise; every gradient below that layer
+    # then moves by ~1e-3 on either implementation (tests/test_model_gpu.py::test_train_step_parity): wider floor for such cases only
+    gate_noise = min(margins) < 5e-6
+    floor = 5e-3 if gate_noise else 2e-4
     worst = 0.0
     for n, ref_norm, ref_head in zip([str(s) for s in g["grad_names"]], g["grad_norms"], g["grad_heads"]):
         p = params[n]
@@ -152,17 +158,17 @@ def test_threshold_training_forward_matches_reference(name):
             continue
         assert p.grad is not None, n
         gf = p.grad.detach().flatten().cpu()
-        np.testing.assert_allclose(float(gf.double().norm()), ref_norm, rtol=2e-3, atol=1e-6, err_msg=n)
+        np.testing.assert_allclose(float(gf.double().norm()), ref_norm, rtol=5e-3 if gate_noise else 2e-3, atol=1e-6, err_msg=n)
         m = min(8, gf.numel())
-        np.testing.assert_allclose(gf[:m].numpy(), ref_head[:m], rtol=5e-3, atol=5e-3 * float(np.abs(ref_head[:m]).max()) + 2e-6, err_msg=n)
+        np.testing.assert_allclose(gf[:m].numpy(), ref_head[:m], rtol=5e-3, atol=(2e-2 if gate_noise else 5e-3) * float(np.abs(ref_head[:m]).max()) + 2e-6, err_msg=n)
         g64 = sd64[n].grad.flatten()
         denom = float(g64.norm())
         if denom > 1e-6:
             err_hip = float((gf.double() - g64).norm()) / denom
             err_cpu = float((sd32[n].grad.flatten().double() - g64).norm()) / denom
-            assert err_hip <= max(4.0 * err_cpu, 2e-4), (n, err_hip, err_cpu)
+            assert err_hip <= max(4.0 * err_cpu, floor), (n, err_hip, err_cpu, min(margins))
             worst = max(worst, err_hip)
-    print(f"[{name}] worst relative gradient error vs the fp64 oracle: {worst:.2e}")
+    print(f"[{name}] worst relative gradient error vs the fp64 oracle: {worst:.2e} (relu gate at noise level: {gate_noise}, min margin {min(margins):.1e})")
 
 
 @pytest.mark.parametrize("name", ["micro_thr1", "micro_thr2"])

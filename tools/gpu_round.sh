@@ -4,7 +4,7 @@ TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $ROOT/gpurun_out
 cd $ROOT
-timeout -k 10 900 python -m pytest tests -m gpu -x -q "$@" > gpurun_out/${TAG}_tests.log 2>&1
+timeout -k 10 900 python -m pytest tests -m gpu -q "$@" > gpurun_out/${TAG}_tests.log 2>&1
 echo "tests rc=$?"; tail -3 gpurun_out/${TAG}_tests.log
 timeout -k 10 300 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err || { tail -5 gpurun_out/${TAG}_bench.err; exit 1; }
 cat gpurun_out/${TAG}_bench.json | cut -c1-600
