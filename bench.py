@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--reference-quirk", action="store_true",
                     help="c5 only: keep int(196 * ratio) = 58 tokens of the 576 (the reference hard-codes init_n = 14*14, dynamic_vit.py:828,852) "
                          "instead of int(576 * ratio) = 172")
+    ap.add_argument("--gemm-shapes-out", default=None, help="write the in-step per-shape GEMM times (layout M N K launches us TFLOP/s) to this file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented pass (no per-kernel figures in the line)")
     ap.add_argument("--time-kernels-in-region", action="store_true",
@@ -88,6 +89,7 @@ class KernelTimer:
 
     def __init__(self):
         self.records = {}   # key -> list of (start, end, work)
+        self.shapes = {}    # (layout, M, N, K) -> list of (start, end): per-shape in-step GEMM times (--gemm-shapes-out)
         self.enabled = False
 
     def wrap(self, ops):
@@ -102,6 +104,7 @@ class KernelTimer:
             out = orig_gemm(layout, A, lda, B, ldb, C, ldc, M, N, K, *a, **kw)
             e.record()
             timer.records.setdefault(("gemm_f32", ("NT", "NN", "TN")[layout]), []).append((s, e, 2.0 * M * N * K))
+            timer.shapes.setdefault((("NT", "NN", "TN")[layout], M, N, K), []).append((s, e))
             return out
 
         def gather_pack(x, ids):
@@ -145,6 +148,7 @@ class KernelTimer:
             out = orig_wgrad(dy, x, dW, *a, **kw)
             e.record()
             timer.records.setdefault(("gemm_f32", "TN"), []).append((s, e, 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1]))
+            timer.shapes.setdefault(("TN", dy.shape[1], x.shape[1], dy.shape[0]), []).append((s, e))
             return out
 
         ops.linear_wgrad = linear_wgrad
@@ -438,6 +442,15 @@ def main():
                                                             "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in gemms.items()},
                                 "gemm_share_of_step": round(tot_ms / (1000.0 * (instr_elapsed or elapsed)), 4),
                                 "gemm_family_TFLOP/s": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2)}
+        if args.gemm_shapes_out and timer.shapes:
+            with open(args.gemm_shapes_out, "w") as f:
+                f.write(f"# in-step GEMM times per shape (HIP events, instrumented pass of {args.steps} steps): layout M N K launches/step us TFLOP/s ms/step\n")
+                rows = []
+                for (lay, M, N, K), recs in timer.shapes.items():
+                    us = sum(a.elapsed_time(b) for a, b in recs) * 1e3 / len(recs)
+                    rows.append((len(recs) * us / args.steps / 1e3, lay, M, N, K, len(recs) / args.steps, us, 2.0 * M * N * K / us / 1e6))
+                for ms, lay, M, N, K, n, us, tf in sorted(rows, reverse=True):
+                    f.write(f"{lay} {M:6d} {N:5d} {K:6d} {n:5.1f} {us:8.1f} {tf:7.1f} {ms:7.3f}\n")
         line["c_abi_calls_per_step"] = round(timer.launch_calls / args.steps, 1)
         sc = summ.get(("scatter_unpack", ""))
         if sc:

@@ -681,7 +681,9 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 struct Tile { int bm, bn; float penalty; };
 inline Tile pick_tile(int M, int N) {
     static const int forced = [] { const char* e = getenv("D2S_GEMM_TILE"); return e ? atoi(e) : 0; }();   // tuning aid: 1..4 = candidate index
-    const Tile cand[4] = {{128, 128, 1.00f}, {128, 64, 1.03f}, {64, 128, 1.04f}, {64, 64, 1.05f}};   // re-measured on the FAST kernel (D2S_GEMM_TILE sweep)
+    // per-tile cost factors, re-measured on the [row][k]-image kernel (D2S_GEMM_TILE sweep, profiles/r02_d_gemm_tile_sweep.txt; SQ counters:
+    // the 64x64 tile spends 1.9 vector + 2.1 scalar instructions per MFMA on addressing / loop control, the 128x64 tile 1.1 + 1.1)
+    const Tile cand[4] = {{128, 128, 1.00f}, {128, 64, 1.04f}, {64, 128, 1.05f}, {64, 64, 1.10f}};
     if (forced >= 1 && forced <= 4) return cand[forced - 1];
     Tile best = cand[0];
     float best_cost = 1e30f;
