@@ -630,6 +630,46 @@ __global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(GemmArgs p, cons
     *cp = v;
 }
 
+// dst[c][r] = src[r][c] for a [R][C] matrix (weights): 64x64 tiles through LDS, 16-byte accesses on both sides.  Used to keep a
+// k-contiguous copy W^T of a Linear weight so that the input-gradient GEMM dx = dy W runs in the NT layout (both operands k-contiguous:
+// the [row][k] LDS image with 16-byte LDS traffic) instead of NN.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
+    __shared__ float t[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + i * 256, r = f >> 4, c4 = (f & 15) * 4;
+        if (r0 + r < R) {
+            if (c0 + c4 + 3 < C && ((C & 3) == 0)) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)(r0 + r) * C + c0 + c4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[r][c4 + j] = v[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c0 + c4 + j < C) t[r][c4 + j] = src[(long)(r0 + r) * C + c0 + c4 + j];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + i * 256, c = f >> 4, r4 = (f & 15) * 4;
+        if (c0 + c < C) {
+            if (r0 + r4 + 3 < R && ((R & 3) == 0)) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = t[r4 + j][c];
+                *reinterpret_cast<f32x4*>(dst + (long)(c0 + c) * R + r0 + r4) = v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (r0 + r4 + j < R) dst[(long)(c0 + c) * R + r0 + r4 + j] = t[r4 + j][c];
+            }
+        }
+    }
+}
+
 // Column sums (bias gradients): out[n] (+)= sum_m X[m][n].  Stage 1: each block owns 64 columns and a row slice.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long ldx, int M, int N,
                                                              int rows_per_slice, float* __restrict__ part) {
@@ -836,7 +876,7 @@ size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K, int mode) {
         const int sl = nt_slices(((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn), K);
         return sl > 1 ? (size_t)sl * M * N * sizeof(float) : 0;
     }
-    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);      // (64x64 wgrad tiles for the small 384x384 weights: measured slower)
     const int slices = splitk_slices(tiles, K);
     size_t bytes = slices <= 1 ? 0 : ((size_t)slices * M * N + (size_t)slices * M) * sizeof(float);   // C slabs + fused bias-gradient slabs
     if (bf16_wgrad(mode))   // + bf16 pieces of both operands + scratch of the separate bias-gradient pass (see gemm_impl)
@@ -982,6 +1022,13 @@ int d2s_linear_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, f
                          int n_out, int n_in, int accumulate, int mode, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     return gemm_impl(2, dy, lddy, x, ldx, dW, lddw, n_out, n_in, tokens, EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0,
                      accumulate, workspace, workspace_bytes, stream, db, mode);
+}
+
+// dst[C][R] = src[R][C]^T (dense row-major): the k-contiguous copy of a Linear weight for the input-gradient GEMM.
+int d2s_transpose_f32(const float* src, float* dst, int R, int C, hipStream_t stream) {
+    if (!src || !dst || R <= 0 || C <= 0) return D2S_ERR_ARG;
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, stream, src, dst, R, C);
+    return d2s_check_launch();
 }
 
 size_t d2s_colsum_workspace_bytes(int M, int N) {

@@ -62,6 +62,7 @@ class ParamArena:
             gv = self.grads[o:o + s].view(p.shape)
             self.grad_views[n] = gv
             ops.register_grad_buffer(p, gv)
+        ops.register_weight_arena(self.params)       # weights at stable addresses: their W^T copies may be cached (ops.linear_dgrad)
 
     def chunk_range(self, i):
         o = self.offsets[i]
@@ -129,6 +130,7 @@ class FusedAdamW:
         a = self.arena
         ops.adamw_step(a.params, a.grads, self.exp_avg, self.exp_avg_sq, self._desc, a.n_chunks, self.betas[0], self.betas[1],
                        self.eps, self.steps, grad_scale, chunk_steps=self.chunk_steps)
+        ops.bump_weights_epoch()        # the kernel wrote the parameters through raw pointers: cached W^T copies are stale
 
     def zero_grad(self):
         for p in self.arena.params_list:

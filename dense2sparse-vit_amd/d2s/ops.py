@@ -56,6 +56,55 @@ def linear_fwd(x, W, bias=None, epi=None, aux=None, aux_out=None, out=None):
     return gemm(NT, x, K, W, K, out, N, M, N, K, epi, bias, aux, N if aux is not None else 0, aux_out)
 
 
+# ---- k-contiguous copies W^T of Linear weights for the input-gradient GEMM ----
+# dx = dy W is an NN product (W's reduction index is its row index); with W^T [n_in, n_out] at hand it is an NT product, both operands
+# k-contiguous, which the fp32 kernel runs 10-15 % faster on the student's shapes (profiles/r02_e_*).  A weight changes once per
+# optimiser step, so its transpose is rebuilt lazily on the first input-gradient call after a change and reused until the next one:
+# `weights_epoch` is bumped by everything that writes parameters behind torch's back (the fused AdamW kernel); in-place torch writes
+# (load_state_dict, torch optimisers) show up in the tensor's version counter.
+# Only weights that live in a registered parameter arena (d2s.engine.ParamArena) take this path: their addresses are stable and unique for
+# the arena's lifetime, whereas the address of a free-standing tensor can be recycled for another tensor with the same shape and version.
+weights_epoch = 0
+_WT = {}                        # data_ptr -> (epoch, version, shape, W^T tensor)
+_WT_ARENAS = []                 # (weakref to the arena tensor, first byte, one past the last byte)
+
+
+def register_weight_arena(arena_tensor):
+    import weakref
+    _WT_ARENAS[:] = [a for a in _WT_ARENAS if a[0]() is not None]
+    lo = arena_tensor.data_ptr()
+    hi = lo + arena_tensor.numel() * 4
+    for key in [k for k in _WT if lo <= k < hi]:       # an earlier arena's entries at recycled addresses
+        del _WT[key]
+    _WT_ARENAS.append((weakref.ref(arena_tensor), lo, hi))
+
+
+def _in_weight_arena(ptr):
+    for ref, lo, hi in _WT_ARENAS:
+        if lo <= ptr < hi and ref() is not None:
+            return True
+    return False
+_DGRAD_NT_MIN_ROWS = int(os.environ.get("D2S_DGRAD_NT_MIN_ROWS", "4096"))      # below this the transpose costs more than it saves
+
+
+def bump_weights_epoch():
+    global weights_epoch
+    weights_epoch += 1
+
+
+def transposed_weight(W):
+    key = W.data_ptr()
+    ent = _WT.get(key)
+    if ent is not None and ent[0] == weights_epoch and ent[1] == W._version and ent[2] == tuple(W.shape):
+        return ent[3]
+    Wt = ent[3] if (ent is not None and ent[2] == tuple(W.shape)) else torch.empty((W.shape[1], W.shape[0]), dtype=torch.float32, device=W.device)
+    lib.call("d2s_transpose_f32", lib.ptr(W), lib.ptr(Wt), W.shape[0], W.shape[1])
+    if len(_WT) > 4096:         # models come and go in a test process: do not let stale entries pile up
+        _WT.clear()
+    _WT[key] = (weights_epoch, W._version, tuple(W.shape), Wt)
+    return Wt
+
+
 def linear_dgrad(dy, W, epi=EPI_NONE, aux=None, out=None):
     """dx[M,K] = epi(dy[M,N] @ W[N,K])."""
     _f32(dy), _f32(W)
@@ -63,6 +112,8 @@ def linear_dgrad(dy, W, epi=EPI_NONE, aux=None, out=None):
     K = W.shape[1]
     if out is None:
         out = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    if get_gemm_mode() == GEMM_EXACT and M >= _DGRAD_NT_MIN_ROWS and (N % 16 == 0) and (K % 4 == 0) and _in_weight_arena(W.data_ptr()):
+        return gemm(NT, dy, N, transposed_weight(W), N, out, K, M, K, N, epi, None, aux, K if aux is not None else 0)
     return gemm(NN, dy, N, W, K, out, K, M, K, N, epi, None, aux, K if aux is not None else 0)
 
 

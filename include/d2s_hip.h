@@ -56,6 +56,9 @@ int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb,
 size_t d2s_linear_wgrad_workspace_bytes(int tokens, int n_out, int n_in, int mode);
 int d2s_linear_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, float* db, int tokens,
                          int n_out, int n_in, int accumulate, int mode, void* workspace, size_t workspace_bytes, d2s_stream_t stream);
+/* dst[C][R] = src[R][C]^T: a k-contiguous copy W^T of an nn.Linear weight, so that autograd's dx = dy W (vit_models/dynamic_vit.py:169-175
+ * backward) can run in the NT layout - both operands k-contiguous - instead of NN. */
+int d2s_transpose_f32(const float* src, float* dst, int R, int C, d2s_stream_t stream);
 /* out[n] (+)= sum_m X[m][n]: bias gradients where no weight gradient is wanted. */
 size_t d2s_colsum_workspace_bytes(int M, int N);
 int d2s_colsum_f32(const float* X, long ldx, int M, int N, float* out, int accumulate, void* workspace,

@@ -38,6 +38,8 @@ for L, M, N, K, what in shapes:
         A = torch.randn(M, K, device=dev); Bm = torch.randn(K, N, device=dev); lda, ldb = K, N
     else:
         A = torch.randn(K, M, device=dev); Bm = torch.randn(K, N, device=dev); lda, ldb = M, N
+    if os.environ.get("D2S_BENCH_ZEROS") == "1":      # power / clock probe: all-zero operands toggle no multiplier bits
+        A.zero_(); Bm.zero_()
     C = torch.empty(M, N, device=dev)
     bias = torch.randn(N, device=dev)
     epi = ops.EPI_BIAS if L == "NT" else ops.EPI_NONE
