@@ -248,7 +248,7 @@ def cpu_baseline(keep, batch=32, warm=2, steps=10):
                 sample=f"{steps} full train steps of the CPU oracle at batch {batch} (same model/config, fp32), after {warm} warm-up; {dt:.1f} s")
 
 
-PMC_FILE = "r01_g_pmc_traffic.json"
+PMC_FILE = "r02_g_pmc_traffic.json"
 
 
 def pmc_traffic(kernel_prefix):
@@ -430,8 +430,11 @@ def main():
             mode_key = "exact" if (dom[1] == "TN" and args.gemm_mode == "split") else args.gemm_mode
             kern, instr, peak = GEMM_MODE_ROOFLINE[mode_key]
             assert ach <= peak, f"achieved {ach:.1f} TFLOP/s above the {peak} peak: wrong peak or wrong FLOP count"
-            pmc_prefix = {"NT": "gemm_f32_kernel<0, 0,", "NN": "gemm_f32_kernel<0, 1,", "TN": "gemm_f32_kernel<1, 1,"}[dom[1]] if mode_key == "exact" \
+            # NT / NN run in the [row][k]-image kernel (template argument = B layout), TN (wgrad) in the [k][row]-image kernel
+            pmc_prefix = {"NT": "gemm_f32_rk_kernel<0,", "NN": "gemm_f32_rk_kernel<1,", "TN": "gemm_f32_kernel<1, 1,"}[dom[1]] if mode_key == "exact" \
                 else "gemm_pieces_nt_kernel"
+            if mode_key == "exact" and dom[1] != "TN":
+                kern = "gemm_f32_rk_kernel"
             line["roofline"] = {"bound": "mfma", "kernel": f"{kern}, {dom[1]} layout ({instr})",
                                 "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                                 "frac": round(ach / peak, 4), "traffic": pmc_traffic(pmc_prefix),

@@ -1,0 +1,21 @@
+#!/bin/bash
+# End-of-round evidence in one gpurun call: GPU suite, default bench line, rocprofv3 kernel stats, PMC traffic passes, the other BASELINE
+# configs and arithmetic modes on one GPU.  usage: tools/evidence_round.sh <tag>
+TAG=$1
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+cd $ROOT && bash tools/gpu_round.sh $TAG || exit 1
+bash tools/pmc_traffic.sh ${TAG} || exit 1
+cd $ROOT
+for c in c2 c3 c4 c5; do timeout -k 10 300 python bench.py --config $c --steps 8 --warmup 3 > gpurun_out/${TAG}_bench_$c.json 2> gpurun_out/${TAG}_bench_$c.err || tail -3 gpurun_out/${TAG}_bench_$c.err; done
+timeout -k 10 300 python bench.py --config c5 --reference-quirk --steps 8 --warmup 3 > gpurun_out/${TAG}_bench_c5_quirk.json 2>/dev/null
+timeout -k 10 300 python bench.py --gemm-mode split --no-cpu-baseline > gpurun_out/${TAG}_bench_split.json 2>/dev/null
+timeout -k 10 300 python bench.py --gemm-mode bf16 --no-cpu-baseline > gpurun_out/${TAG}_bench_bf16.json 2>/dev/null
+TAG_=$TAG python - <<'PY'
+import json, glob, os
+for f in sorted(glob.glob("gpurun_out/%s_bench*.json" % os.environ.get("TAG_", ""))):
+    try:
+        d = json.load(open(f)); r = d.get("roofline", {})
+        print(os.path.basename(f), d["value"], d["ms_per_step"], r.get("kernel"), r.get("achieved"), r.get("peak"), r.get("frac"))
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
