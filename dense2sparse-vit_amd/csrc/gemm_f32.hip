@@ -670,6 +670,37 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// Batched form: one launch transposes every weight matrix of a parameter arena into a second arena.  desc[block] = {source offset,
+// destination offset (floats, relative to the two bases), R, C, r0, c0}: the block moves the 64x64 tile at (r0, c0) of that matrix.
+struct TransposeTile { long src_off, dst_off; int R, C, r0, c0; };
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base,
+                                                                const TransposeTile* __restrict__ desc) {
+    __shared__ float t[64][65];
+    const TransposeTile d = desc[blockIdx.x];
+    const float* src = src_base + d.src_off;
+    float* dst = dst_base + d.dst_off;
+    const int R = d.R, C = d.C, r0 = d.r0, c0 = d.c0, tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + i * 256, r = f >> 4, c4 = (f & 15) * 4;
+        if (r0 + r < R) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c0 + c4 + j < C) t[r][c4 + j] = src[(long)(r0 + r) * C + c0 + c4 + j];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + i * 256, c = f >> 4, r4 = (f & 15) * 4;
+        if (c0 + c < C) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (r0 + r4 + j < R) dst[(long)(c0 + c) * R + r0 + r4 + j] = t[r4 + j][c];
+        }
+    }
+}
+
 // Column sums (bias gradients): out[n] (+)= sum_m X[m][n].  Stage 1: each block owns 64 columns and a row slice.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long ldx, int M, int N,
                                                              int rows_per_slice, float* __restrict__ part) {
@@ -1028,6 +1059,14 @@ int d2s_linear_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, f
 int d2s_transpose_f32(const float* src, float* dst, int R, int C, hipStream_t stream) {
     if (!src || !dst || R <= 0 || C <= 0) return D2S_ERR_ARG;
     hipLaunchKernelGGL(transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, stream, src, dst, R, C);
+    return d2s_check_launch();
+}
+
+// n_tiles descriptors of 6 fields {long src_off, long dst_off, int R, int C, int r0, int c0} (32 bytes each) in device memory.
+int d2s_transpose_batched_f32(const float* src_base, float* dst_base, const void* tile_desc, int n_tiles, hipStream_t stream) {
+    if (!src_base || !dst_base || !tile_desc || n_tiles <= 0) return D2S_ERR_ARG;
+    static_assert(sizeof(TransposeTile) == 32, "descriptor layout is part of the C ABI");
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3(n_tiles), dim3(256), 0, stream, src_base, dst_base, static_cast<const TransposeTile*>(tile_desc));
     return d2s_check_launch();
 }
 

@@ -101,6 +101,7 @@ class FusedAdamW:
         self.chunk_steps = torch.zeros(arena.n_chunks, dtype=torch.int32, device=arena.params.device)
         self._desc = None
         self._dirty = True
+        self._wt = None
 
     def set_lrs(self, predictor_lr, backbone_lr):
         self.group_lr.update(predictor=predictor_lr, base_no_decay=backbone_lr, base_decay=backbone_lr)
@@ -130,7 +131,10 @@ class FusedAdamW:
         a = self.arena
         ops.adamw_step(a.params, a.grads, self.exp_avg, self.exp_avg_sq, self._desc, a.n_chunks, self.betas[0], self.betas[1],
                        self.eps, self.steps, grad_scale, chunk_steps=self.chunk_steps)
-        ops.bump_weights_epoch()        # the kernel wrote the parameters through raw pointers: cached W^T copies are stale
+        ops.bump_weights_epoch()        # the kernel wrote the parameters through raw pointers: cached W^T copies are stale ...
+        if self._wt is None:            # ... and are rebuilt for the whole arena in one launch (the input-gradient GEMMs read them)
+            self._wt = ops.TransposedArena(a.params, list(zip(a.params_list, a.offsets)))
+        self._wt.refresh()
 
     def zero_grad(self):
         for p in self.arena.params_list:

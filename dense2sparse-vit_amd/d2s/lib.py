@@ -24,6 +24,7 @@ _SIGS = {
     "d2s_batchnorm_fwd": (I, [P, P, P, P, P, P, P, P, L, I, F, F, I, P, Z]),
     "d2s_batchnorm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, L, I, P, Z]),
     "d2s_transpose_f32": (I, [P, P, I, I]),
+    "d2s_transpose_batched_f32": (I, [P, P, P, I]),
     "d2s_colsum_workspace_bytes": (Z, [I, I]),
     "d2s_colsum_f32": (I, [P, L, I, I, P, I, P, Z]),
     "d2s_layernorm_fwd": (I, [P, L, L, L, L, P, P, P, P, P, L, I, F]),

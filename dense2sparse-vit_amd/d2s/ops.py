@@ -105,6 +105,40 @@ def transposed_weight(W):
     return Wt
 
 
+class TransposedArena:
+    """W^T copies of every 2-D weight of a parameter arena, rebuilt by ONE kernel launch per optimiser step (d2s.engine.FusedAdamW calls
+    refresh() right after the update) instead of one small launch per weight on its first input-gradient use."""
+
+    def __init__(self, arena_params, weights):
+        """weights: list of (Parameter living in arena_params, its arena offset in floats); only 2-D ones are kept.  The Parameter objects
+        (not .data aliases) are held so that refresh() records the version counter the autograd Functions will see."""
+        import numpy as np
+        self.src = arena_params
+        mats = [(w, off) for w, off in weights if w.dim() == 2]
+        total = sum(w.numel() for w, _ in mats)
+        self.dst = torch.empty(max(total, 1), dtype=torch.float32, device=arena_params.device)
+        rows, self.entries, doff = [], [], 0
+        for w, off in mats:
+            R, C = w.shape
+            self.entries.append((w, self.dst[doff:doff + R * C].view(C, R)))
+            for r0 in range(0, R, 64):
+                for c0 in range(0, C, 64):
+                    rows.append((off, doff, R, C, r0, c0))
+            doff += R * C
+        desc = np.zeros(len(rows), dtype=[("s", "<i8"), ("d", "<i8"), ("R", "<i4"), ("C", "<i4"), ("r0", "<i4"), ("c0", "<i4")])
+        for i, r in enumerate(rows):
+            desc[i] = r
+        self.n_tiles = len(rows)
+        self.desc = torch.from_numpy(desc.view(np.uint8).copy()).to(arena_params.device) if rows else None
+
+    def refresh(self):
+        if not self.n_tiles:
+            return
+        lib.call("d2s_transpose_batched_f32", lib.ptr(self.src), lib.ptr(self.dst), lib.ptr(self.desc), self.n_tiles)
+        for w, wt in self.entries:
+            _WT[w.data_ptr()] = (weights_epoch, w._version, tuple(w.shape), wt)
+
+
 def linear_dgrad(dy, W, epi=EPI_NONE, aux=None, out=None):
     """dx[M,K] = epi(dy[M,N] @ W[N,K])."""
     _f32(dy), _f32(W)

@@ -59,6 +59,9 @@ int d2s_linear_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, f
 /* dst[C][R] = src[R][C]^T: a k-contiguous copy W^T of an nn.Linear weight, so that autograd's dx = dy W (vit_models/dynamic_vit.py:169-175
  * backward) can run in the NT layout - both operands k-contiguous - instead of NN. */
 int d2s_transpose_f32(const float* src, float* dst, int R, int C, d2s_stream_t stream);
+/* every weight of a parameter arena in one launch: tile_desc = n_tiles x {long src_off, long dst_off, int R, int C, int r0, int c0}
+ * (offsets in floats from the two bases; one 64x64 tile per descriptor), refreshed once per optimiser step */
+int d2s_transpose_batched_f32(const float* src_base, float* dst_base, const void* tile_desc, int n_tiles, d2s_stream_t stream);
 /* out[n] (+)= sum_m X[m][n]: bias gradients where no weight gradient is wanted. */
 size_t d2s_colsum_workspace_bytes(int M, int N);
 int d2s_colsum_f32(const float* X, long ldx, int M, int N, float* out, int accumulate, void* workspace,
