@@ -194,6 +194,54 @@ __global__ __launch_bounds__(256) void half_mean_concat_kernel(const float* __re
         }
 }
 
+// 16-byte form (C a multiple of 8): a lane owns 4 consecutive columns, a wave instruction moves 1 KB of a row (the scalar form
+// below moved 256-byte segments: 2.9 TB/s on the 25088 x 1536 predictor activation), the four waves of a workgroup interleave over the tokens.
+__global__ __launch_bounds__(256) void half_mean_concat_vec_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                                   float* __restrict__ out, int T, int C) {
+    __shared__ f32x4 red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = C >> 1;
+    const int chunks = (half + 255) >> 8;
+    const bool second = (int)blockIdx.x >= chunks;
+    const int c = (second ? half : 0) + ((int)blockIdx.x - (second ? chunks : 0)) * 256 + lane * 4;
+    const bool ok = c < (second ? C : half);
+    const long base = (long)blockIdx.y * T * C + c;
+    if (!second) {
+        if (ok)
+#pragma unroll 4
+            for (int t = wave; t < T; t += 4) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(x + base + (long)t * C);
+                if (mask) {
+                    const f32x4 m = *reinterpret_cast<const f32x4*>(mask + base + (long)t * C);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = m[j] > 0.f ? v[j] : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(out + base + (long)t * C) = v;
+            }
+        return;
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (ok)
+#pragma unroll 8
+        for (int t = wave; t < T; t += 4) s += *reinterpret_cast<const f32x4*>(x + base + (long)t * C);
+    red[wave][lane] = s;
+    __syncthreads();
+    f32x4 mean;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mean[j] = ((red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j])) / (float)T;
+    if (ok)
+#pragma unroll 4
+        for (int t = wave; t < T; t += 4) {
+            f32x4 v = mean;
+            if (mask) {
+                const f32x4 m = *reinterpret_cast<const f32x4*>(mask + base + (long)t * C);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = m[j] > 0.f ? v[j] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(out + base + (long)t * C) = v;
+        }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // patch extraction (im2col of the stride-16 conv, dynamic_vit.py:298,305): image [B,Cin,H,W] -> [B*T, Cin*P*P]
 // ---------------------------------------------------------------------------------------------------------
@@ -311,6 +359,12 @@ int d2s_scatter_unpack_bwd(const float* g, const long long* ids, float* dx, int 
 
 int d2s_half_mean_concat(const float* x, const float* relu_mask_src, float* out, int B, int T, int C, hipStream_t stream) {
     if (!x || !out || B <= 0 || T <= 0 || C <= 0 || (C & 1)) return D2S_ERR_ARG;
+    const bool vec = (C % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(relu_mask_src)) & 15) == 0;
+    if (vec) {
+        const int chunks = ((C >> 1) + 255) >> 8;
+        hipLaunchKernelGGL(half_mean_concat_vec_kernel, dim3(2 * chunks, B), dim3(256), 0, stream, x, relu_mask_src, out, T, C);
+        return d2s_check_launch();
+    }
     const int chunks = ((C >> 1) + 63) >> 6;
     hipLaunchKernelGGL(half_mean_concat_kernel, dim3(2 * chunks, B), dim3(256), 0, stream, x, relu_mask_src, out, T, C);
     return d2s_check_launch();

@@ -15,6 +15,8 @@ def evaluate_performance(args, model, teacher_model, val_data_loader):
     teacher_model.eval()
     mask_loss_fn = MaskLoss(args, "val")
     metrics = {}
+    thr = getattr(args, "patch_score_threshold", None) is not None
+    keep_ratio_batches = []
     with torch.no_grad():
         for val_inputs, val_labels in val_data_loader:
             val_inputs = val_inputs.to(args.device, non_blocking=True)
@@ -33,7 +35,14 @@ def evaluate_performance(args, model, teacher_model, val_data_loader):
             running_loss += float(loss)
             running_acc += float((preds == val_labels).sum()) / val_labels.shape[0]
             n += 1
+            if thr and model.keep_ratios is not None:                                   # :53-57
+                keep_ratio_batches.append(model.keep_ratios)
     n = max(n, 1)
+    if thr and keep_ratio_batches:                                                      # :59-62
+        allr = torch.stack(keep_ratio_batches)
+        metrics["val_min_keep_ratio"] = float(allr.min())
+        metrics["val_avg_keep_ratio"] = float(allr.mean(dim=1).mean())
+        metrics["val_max_keep_ratio"] = float(allr.max())
     metrics["val_loss"] = running_loss / n
     metrics["val_acc"] = running_acc / n
     metrics["unpruned_acc"] = running_unpruned_acc / n

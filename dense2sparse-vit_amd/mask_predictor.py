@@ -34,7 +34,11 @@ def check_supported(args):
     """Flags whose code path is outside the accelerated hot path fail here, loudly, instead of silently training something else."""
     bad = []
     if args.patch_score_threshold is not None:
-        bad.append("--patch-score-threshold (broken in the reference: dynamic_vit.py:936, losses.py:216-218)")
+        print("Attention: --patch-score-threshold: the reference's losses and inference branch cannot run on this path (losses.py:81,216-218, "
+              "dynamic_vit.py:936); this build follows its training forward line by line and the documented fix for the rest (DESIGN.md section 10)")
+        if len(args.pruning_locs) > 1:
+            bad.append("--patch-score-threshold with more than one pruning stage (ragged inference supports one stage: the reference's "
+                       "second stage cannot run, dynamic_vit.py:945-946)")
     if args.early_exit:
         print("Attention: --early-exit creates the extra head but, as in the reference, nothing calls it (dynamic_vit.py:752-758)")
     if args.random_drop:

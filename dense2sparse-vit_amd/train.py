@@ -25,6 +25,8 @@ def train_one_epoch(args, model, teacher_model, train_data_loader, optimizer, mi
     else:
         mask_loss_fn, backbone_loss_fn = MaskLoss(args, "train"), BackboneLoss(args)
     n_steps = 0
+    thr = getattr(args, "patch_score_threshold", None) is not None
+    keep_ratio_batches = []      # :66-70 - kept on the device; the reference syncs three times per step for these statistics
     for train_step, train_data in enumerate(train_data_loader):
         train_inputs = train_data[0].to(args.device, non_blocking=True)
         train_labels = train_data[1].to(args.device, non_blocking=True)
@@ -47,6 +49,13 @@ def train_one_epoch(args, model, teacher_model, train_data_loader, optimizer, mi
             print(f'training step_{train_step} mask loss: {float(mask_loss):.4f}, train loss: {float(train_loss):.4f}, ')
         running_loss = running_loss + train_loss.detach()
         n_steps += 1
+        if thr and model.keep_ratios is not None:
+            keep_ratio_batches.append(model.keep_ratios)
+    if thr and keep_ratio_batches:                                                                   # :77-80 (the histogram plot is the caller's)
+        allr = torch.stack(keep_ratio_batches)
+        metrics["train_min_keep_ratio"] = float(allr.min())
+        metrics["train_avg_keep_ratio"] = float(allr.mean(dim=1).mean())
+        metrics["train_max_keep_ratio"] = float(allr.max())
     metrics["train_loss"] = float(running_loss) / max(n_steps, 1)                                    # :82
     print(f'train loss: {metrics["train_loss"]:.4f}')
     return metrics

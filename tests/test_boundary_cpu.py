@@ -117,12 +117,13 @@ def test_cli_accepts_every_reference_flag_with_the_same_default():
 def test_cli_rejects_flags_outside_the_path():
     import mask_predictor
     import utils
-    for extra in (["--patch-score-threshold", "0.9"], ["--mask-loss-type", "bce"], ["--use-dp"]):
+    for extra in (["--patch-score-threshold", "0.9", "--pruning-locs", "3", "6", "--keep-ratios", "0.7", "0.5"], ["--mask-loss-type", "bce"], ["--use-dp"]):
         with pytest.raises(SystemExit, match="not on the accelerated path"):
             mask_predictor.check_supported(utils.parse_args(extra))
     a = utils.parse_args([])
     mask_predictor.check_supported(a)
     assert a.mixup == 0.0 and a.cutmix == 0.0
+    mask_predictor.check_supported(utils.parse_args(["--patch-score-threshold", "0.3", "--pruning-locs", "3", "--keep-ratios", "0.5"]))   # one stage: on the path
 
 
 def test_checkpoint_ingestion_matches_reference_fixture():

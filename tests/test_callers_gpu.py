@@ -72,6 +72,17 @@ def test_mask_predictor_cli_runs_the_epoch_loop(capsys):
     assert "Epoch 2/2" in out and "Training complete" in out and "train images/s" in out
 
 
+def test_mask_predictor_cli_with_dynamic_keep_ratio(capsys):
+    """--patch-score-threshold through the entry script: policy-masked training steps (incl. a warm-up epoch), then the ragged
+    inference of evaluate_performance."""
+    import mask_predictor
+    best = mask_predictor.main(["--arch", "deit_tiny", "--pruning-locs", "3", "--keep-ratios", "0.5", "--epochs", "2", "--warmup-steps", "1",
+                                "--batch-size", "4", "--steps-per-epoch", "2", "--val-steps", "1", "--topk-selection", "--patch-score-threshold", "0.3"])
+    out = capsys.readouterr().out
+    assert 0.0 <= best <= 1.0
+    assert "Epoch 2/2" in out and "Training complete" in out
+
+
 def test_mask_loss_mse_branch_matches_reference_fixture():
     """losses.MaskLoss(mask_loss_type='mse') on the HIP path (d2s_kl_rows mode 3 + d2s_gather_renorm) against the reference's own
     output: loss, gradients of both stages' scores, and the metrics keys it writes."""
