@@ -243,7 +243,10 @@ class PredictorFn(torch.autograd.Function):
             width = cur.shape[1]
             ln, mean, rstd = ops.layernorm_fwd(cur, ops.contiguous_map(M, width), lw, lb, M, width, eps, stats=train)
             last = j == nl - 1
-            nxt = ops.linear_fwd(ln, fw, fb, epi=ops.EPI_BIAS if last else ops.EPI_BIAS_RELU)
+            # the predictor's tail (its last two Linear layers, D/2 -> D/4 -> 1: 0.3 % of its FLOPs), like the softmax and the selection
+            # behind it, always runs in exact fp32 - also in the bf16 arithmetic mode (kept-id stability)
+            with ops.gemm_mode(ops.GEMM_EXACT if j >= nl - 2 else ops.get_gemm_mode()):
+                nxt = ops.linear_fwd(ln, fw, fb, epi=ops.EPI_BIAS if last else ops.EPI_BIAS_RELU)
             saved += [cur, ln, mean, rstd]
             cur = nxt
         scores = cur.view(B, T)
@@ -271,8 +274,9 @@ class PredictorFn(torch.autograd.Function):
             base = 4 + 4 * j
             width = cur.shape[1]
             # d is the gradient w.r.t. the pre-activation of layer j's Linear (the ReLU mask was applied upstream)
-            grads[base + 2], grads[base + 3] = ops.linear_param_grads(d, ln, fw, fb, want[base + 2], want[base + 3])
-            dln = ops.linear_dgrad(d, fw)
+            with ops.gemm_mode(ops.GEMM_EXACT if j >= nl - 2 else ops.get_gemm_mode()):      # same arithmetic as the forward of this layer
+                grads[base + 2], grads[base + 3] = ops.linear_param_grads(d, ln, fw, fb, want[base + 2], want[base + 3])
+                dln = ops.linear_dgrad(d, fw)
             dcur = torch.empty((M, width), dtype=torch.float32, device=dev)
             dlw = ops.grad_buffer(lw) if (want[base] or want[base + 1]) else None
             dlb = ops.grad_buffer(lb) if dlw is not None else None

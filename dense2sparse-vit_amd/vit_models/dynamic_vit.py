@@ -343,6 +343,9 @@ class VisionTransformerDiffPruning(_ViTBase):
         self.patch_score_threshold = patch_score_threshold
         self.keep_ratios = None          # :886 / :941 - per-image kept fraction of the last thresholded stage (device tensor)
         self.cu_seqlens = self.ragged_row_src = None     # ragged inference: packed-row offsets per image / source token of each row
+        # replay of a recorded selection (analysis / tests): a list of int64 [B, k_i] kept-id tensors, one per stage, used INSTEAD of the
+        # top-k of this forward's scores (which are still computed and returned); None = normal operation
+        self.kept_token_override = None
         self.unpruned = False
         self.distill = distill
         self.pruning_loc, self.token_ratio = pruning_loc, token_ratio
@@ -383,6 +386,11 @@ class VisionTransformerDiffPruning(_ViTBase):
                 num_keep_node = int(self.init_n * self.token_ratio[p_count])   # :852
                 pred_logits, pred_score = self.score_predictor[p_count].forward_tokens(x)   # :855
                 kept, dropped = DF.select_topk(pred_score, num_keep_node)     # :858-862
+                if self.kept_token_override is not None:
+                    kept = self.kept_token_override[p_count].to(device=x.device, dtype=torch.int64).contiguous()
+                    assert kept.shape == (x.shape[0], num_keep_node), "override ids must be [B, int(init_n * ratio)]"
+                    keep_mask = DF.ops.patch_keep_mask(kept, x.shape[1] - 1)
+                    dropped = torch.nonzero(keep_mask == 0)[:, 1].reshape(x.shape[0], -1)
                 self.kept_token_indices.append(kept)
                 self.dropped_token_indices.append(dropped)
                 self.pred_logits.append(pred_logits)

@@ -475,71 +475,103 @@ def test_split_gemm_mode_keeps_fp32_parity(name):
 
 @pytest.mark.parametrize("name", ["small_k50", "small_3stage", "base384_k30"])
 def test_bf16_gemm_mode_model_parity(name):
-    """GEMM mode 2 (bf16 operands, fp32 accumulation, bf16 attention: BASELINE config 5's regime) at model level, with the contract of
-    SURVEY 8c: the predictor tail, softmax and selection stay fp32, so the kept ids must be bit-exact on every image whose k / k+1
-    probability margin (computed from the reference's own scores in the fixture) exceeds twice the perturbation the bf16 arithmetic
-    put on that image's probabilities; images below that are reported, not asserted.  Where the ids agree: logits rtol 2e-2 (atol 2 %
-    of the largest logit), losses rtol 2e-2, every parameter gradient within 10 % in relative L2 of the fp32 oracle gradient (bf16
-    rounding 2^-9 per operand through 12 layers; the measured worst case is printed)."""
+    """GEMM mode 2 (bf16 operands, fp32 accumulation, bf16 attention: BASELINE config 5's regime) at model level, SURVEY 8c's contract.
+
+    Phase 1, free running.  The predictor's tail, the softmax and the selection stay fp32; the kept ids must be bit-exact on every image
+    whose k / k+1 probability margin (from the reference's own scores in the fixture) exceeds twice the perturbation the bf16 arithmetic
+    put on that image's probabilities; images below that are reported, not asserted (with random-init weights the margins are 1e-5 and
+    below, so most images are of that kind) - but even there the selections may only differ near the boundary: at least 90 % of the
+    kept ids agree with the reference's.
+    Phase 2, the reference's selection replayed (`kept_token_override`): with identical ids everything downstream is comparable -
+    logits rtol 2e-2 (atol 2 % of the largest logit), losses rtol 2e-2, every parameter gradient within 25 % relative L2 of the fp32
+    oracle gradient (median under 8 %), cosine > 0.97 and norm within 10 % (bf16 rounding, 2^-9 per operand, through 12 layers at batch 1-2;
+    the measured figures are printed)."""
     from d2s.engine import TrainStep
     from d2s import ops
     dev = torch.device("cuda:0")
     case = cases.MODEL_CASES[name]
     cfg = case["cfg"]
     g = cases.load_golden("model_" + name)
-    ops.set_gemm_mode(ops.GEMM_BF16)
-    try:
-        student, teacher, sd_s, sd_t = build_models(case, dev)
-        x, y = _t(cases.make_images(case)), _t(cases.make_labels(case))
-        ts = TrainStep(student, teacher, make_args(cfg), warmup_steps=0)
-        student.train()
-        loss, info = ts.forward_losses(x.to(dev), y.to(dev))
-        ts.opt.zero_grad()
-        loss.backward()
-        torch.cuda.synchronize()
-    finally:
-        ops.set_gemm_mode(ops.GEMM_EXACT)
+    x, y = _t(cases.make_images(case)), _t(cases.make_labels(case))
     B = x.shape[0]
-    same = np.ones(B, bool)          # images whose ids agree with the reference on every stage so far
+    nstage = len(cfg["pruning_loc"])
+
+    def run(override):
+        ops.set_gemm_mode(ops.GEMM_BF16)
+        try:
+            student, teacher, sd_s, sd_t = build_models(case, dev)
+            student.kept_token_override = override
+            ts = TrainStep(student, teacher, make_args(cfg), warmup_steps=0)
+            student.train()
+            loss, info = ts.forward_losses(x.to(dev), y.to(dev))
+            ts.opt.zero_grad()
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.set_gemm_mode(ops.GEMM_EXACT)
+        return student, info, sd_s, sd_t
+
+    # ---- phase 1: free running
+    student, info, sd_s, sd_t = run(None)
+    same = np.ones(B, bool)
     undecided = []
     for i, kept in enumerate(info["kept"]):
         ref_scores, got_scores = _t(g[f"pred_logits_{i}"]), info["pred_logits"][i].detach().cpu()
-        p_ref, p_got = torch.softmax(ref_scores, dim=-1), torch.softmax(got_scores, dim=-1)
         k = kept.shape[1]
-        srt = torch.sort(p_ref, dim=-1, descending=True)[0]
-        margin = (srt[:, k - 1] - srt[:, k]).numpy() if k < srt.shape[1] else np.full(B, np.inf)
-        pert = (p_got - p_ref).abs().max(dim=-1)[0].numpy()
         eq = (kept.cpu().numpy() == g[f"kept_{i}"]).all(axis=1)
-        for b in range(B):
-            if not same[b]:
-                continue                              # an earlier stage already differs: this stage saw other tokens
-            if margin[b] > 2.0 * pert[b]:
-                assert eq[b], f"stage {i} image {b}: ids differ although margin {margin[b]:.3e} > 2 x perturbation {pert[b]:.3e}"
-            elif not eq[b]:
-                undecided.append((i, b, float(margin[b]), float(pert[b])))
+        if same.any():
+            p_ref, p_got = torch.softmax(ref_scores, dim=-1), torch.softmax(got_scores, dim=-1)
+            srt = torch.sort(p_ref, dim=-1, descending=True)[0]
+            margin = (srt[:, k - 1] - srt[:, k]).numpy() if k < srt.shape[1] else np.full(B, np.inf)
+            pert = (p_got - p_ref).abs().max(dim=-1)[0].numpy()
+            for b in range(B):
+                if not same[b]:
+                    continue                          # an earlier stage already differs: this stage scored other tokens
+                if margin[b] > 2.0 * pert[b]:
+                    assert eq[b], f"stage {i} image {b}: ids differ although margin {margin[b]:.3e} > 2 x perturbation {pert[b]:.3e}"
+                elif not eq[b]:
+                    undecided.append((i, b, float(margin[b]), float(pert[b])))
+                overlap = len(set(kept[b].cpu().tolist()) & set(g[f"kept_{i}"][b].tolist())) / k
+                assert overlap >= 0.9, f"stage {i} image {b}: only {overlap:.2f} of the kept ids agree with the reference"
         same &= eq
-    print(f"[{name} bf16] images with ids equal to the reference on every stage: {int(same.sum())}/{B}; margin-undecided differences: {undecided}")
     lt_ref = g["logits_t"]
     np.testing.assert_allclose(info["logits_t"].cpu().numpy(), lt_ref, rtol=2e-2, atol=2e-2 * float(np.abs(lt_ref).max()))
-    if same.all():
-        ls_ref = g["logits_s"]
-        np.testing.assert_allclose(info["logits_s"].detach().cpu().numpy(), ls_ref, rtol=2e-2, atol=2e-2 * float(np.abs(ls_ref).max()))
-        np.testing.assert_allclose(float(info["mask_loss"]), float(g["mask_loss"]), rtol=2e-2)
-        np.testing.assert_allclose(float(info["backbone_loss"]), float(g["backbone_loss"]), rtol=2e-2)
-        osd = {k: _t(v).requires_grad_(True) for k, v in sd_s.items()}
-        ototal, _ = O.train_step_losses(osd, {k: _t(v) for k, v in sd_t.items()}, cfg, x, y)
-        ototal.backward()
-        worst, worst_name = 0.0, ""
-        for n, p in student.named_parameters():
-            og = osd[n].grad
-            if og is None or float(og.double().norm()) < 1e-6:
-                continue
-            err = float((p.grad.detach().cpu().double().flatten() - og.double().flatten()).norm() / og.double().norm())
-            if err > worst:
-                worst, worst_name = err, n
-            np.testing.assert_allclose(float(p.grad.double().norm()), float(og.double().norm()), rtol=1e-1, err_msg=n)
-        print(f"[{name} bf16] worst relative L2 gradient error vs the fp32 oracle: {worst:.3e} ({worst_name})")
-        assert worst < 1e-1, (worst, worst_name)
+    print(f"[{name} bf16, free running] images with reference ids on every stage: {int(same.sum())}/{B}; differences on margin-undecided images: {undecided}")
+
+    # ---- phase 2: the reference's selection replayed
+    student, info, sd_s, sd_t = run([_t(g[f"kept_{i}"]) for i in range(nstage)])
+    for i, kept in enumerate(info["kept"]):
+        np.testing.assert_array_equal(kept.cpu().numpy(), g[f"kept_{i}"])
+        np.testing.assert_array_equal(np.sort(np.concatenate([kept.cpu().numpy(), student.dropped_token_indices[i].cpu().numpy()], axis=1), axis=1),
+                                      np.tile(np.arange(kept.shape[1] + student.dropped_token_indices[i].shape[1]), (B, 1)))
+    ls_ref = g["logits_s"]
+    np.testing.assert_allclose(info["logits_s"].detach().cpu().numpy(), ls_ref, rtol=2e-2, atol=2e-2 * float(np.abs(ls_ref).max()))
+    for i in range(nstage):
+        pl_ref = g[f"pred_logits_{i}"]
+        np.testing.assert_allclose(info["pred_logits"][i].detach().cpu().numpy(), pl_ref, rtol=2e-2, atol=2e-2 * float(np.abs(pl_ref).max()))
+    np.testing.assert_allclose(float(info["mask_loss"]), float(g["mask_loss"]), rtol=2e-2)
+    np.testing.assert_allclose(float(info["backbone_loss"]), float(g["backbone_loss"]), rtol=2e-2)
+    osd = {k: _t(v).requires_grad_(True) for k, v in sd_s.items()}
+    ototal, oinfo = O.train_step_losses(osd, {k: _t(v) for k, v in sd_t.items()}, cfg, x, y)
+    ototal.backward()
+    errs, worst_name = [], ""
+    for n, p in student.named_parameters():
+        og = osd[n].grad
+        if og is None or float(og.double().norm()) < 1e-6:
+            continue
+        gd, go = p.grad.detach().cpu().double().flatten(), og.double().flatten()
+        err = float((gd - go).norm() / go.norm())
+        cos = float((gd @ go) / (gd.norm() * go.norm()))
+        if not errs or err > max(errs):
+            worst_name = n
+        errs.append(err)
+        # measured on these cases (batch 1-2, so nothing averages out): median 2-4 %, worst 12-17 % on the deepest tensors (patch
+        # embedding, first predictor LayerNorm) after 12 layers of bf16 GEMMs and bf16 attention; direction and size must hold:
+        assert cos > 0.97, (n, cos)
+        np.testing.assert_allclose(float(gd.norm()), float(go.norm()), rtol=1e-1, err_msg=n)
+    print(f"[{name} bf16, reference selection replayed] relative L2 gradient error vs the fp32 oracle: median {np.median(errs):.3e}, "
+          f"worst {max(errs):.3e} ({worst_name})")
+    assert max(errs) < 0.25 and np.median(errs) < 0.08, (max(errs), float(np.median(errs)), worst_name)
 
 
 def test_overfit_one_batch():
