@@ -15,9 +15,6 @@ enum Epi : int {
     EPI_MUL_RELU_MASK = 6, // C = acc * (aux[m][n] > 0)       (aux = saved ReLU output)
     EPI_BIAS_ROWADD = 7,   // C = acc + bias[n] + aux[(m % aux_rows)][n]  (patch embed: + pos_embed rows)
     EPI_ACCUM = 8,         // C += acc
-    EPI_BIAS_GELU_DERIV = 9, // C = gelu(acc + bias[n]); aux_out = gelu'(acc + bias[n]): the derivative is formed where the erf is
-                             // computed anyway, so that the backward's epilogue (EPI_MUL_AUX) is one multiply instead of erf + exp
-    EPI_MUL_AUX = 10,      // C = acc * aux[m][n]
 };
 
 struct GemmArgs {
@@ -46,7 +43,7 @@ __device__ __forceinline__ void store_tile_out(const GemmArgs& p, float* __restr
         const int n = nbase + nt * 32;
         if (n >= p.N) continue;
         float bias = 0.f;
-        if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_DERIV || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_ROWADD)
+        if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_ROWADD)
             bias = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -66,12 +63,6 @@ __device__ __forceinline__ void store_tile_out(const GemmArgs& p, float* __restr
                     if (p.aux_out) p.aux_out[(long)m * p.ldc + n] = v;
                     v = gelu_erf(v);
                 }
-                if (EPI == EPI_BIAS_GELU_DERIV) {
-                    v += bias;
-                    if (p.aux_out) p.aux_out[(long)m * p.ldc + n] = gelu_erf_grad(v);
-                    v = gelu_erf(v);
-                }
-                if (EPI == EPI_MUL_AUX) v *= p.aux[(long)m * p.ldaux + n];
                 if (EPI == EPI_BIAS_RESID) v += bias + p.aux[(long)m * p.ldaux + n];
                 if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(p.aux[(long)m * p.ldaux + n]);
                 if (EPI == EPI_MUL_RELU_MASK) v = p.aux[(long)m * p.ldaux + n] > 0.f ? v : 0.f;
@@ -98,7 +89,7 @@ __device__ __forceinline__ void store_tile_out_lds(const GemmArgs& p, float* __r
     const int half = lane >> 5, l31 = lane & 31;
     const int rr = lane / LPR, c4 = (lane % LPR) * 4;
     const int n = ncol0 + c4;
-    constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_DERIV || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_ROWADD;
+    constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_ROWADD;
     f32x4 bias = {0.f, 0.f, 0.f, 0.f};
     if (HAS_BIAS && p.bias && n < p.N) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
@@ -134,24 +125,13 @@ __device__ __forceinline__ void store_tile_out_lds(const GemmArgs& p, float* __r
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
                 }
-                if (EPI == EPI_BIAS_GELU_DERIV) {
-                    if (p.aux_out) {
-                        f32x4 dv;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) dv[j] = gelu_erf_grad(v[j]);
-                        *reinterpret_cast<f32x4*>(p.aux_out + (long)m * p.ldc + n) = dv;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-                }
-                if (EPI == EPI_BIAS_RESID || EPI == EPI_MUL_GELU_GRAD || EPI == EPI_MUL_RELU_MASK || EPI == EPI_MUL_AUX) {
+                if (EPI == EPI_BIAS_RESID || EPI == EPI_MUL_GELU_GRAD || EPI == EPI_MUL_RELU_MASK) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + (long)m * p.ldaux + n);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (EPI == EPI_BIAS_RESID) v[j] += a[j];
                         if (EPI == EPI_MUL_GELU_GRAD) v[j] *= gelu_erf_grad(a[j]);
                         if (EPI == EPI_MUL_RELU_MASK) v[j] = a[j] > 0.f ? v[j] : 0.f;
-                        if (EPI == EPI_MUL_AUX) v[j] *= a[j];
                     }
                 }
                 if (EPI == EPI_BIAS_ROWADD) {
@@ -180,7 +160,7 @@ __device__ __forceinline__ void store_tile_out_lds16(const GemmArgs& p, float* _
     const int lq = lane >> 4, l15 = lane & 15;
     const int rr = lane / LPR, c4 = (lane % LPR) * 4;
     const int n = ncol0 + c4;
-    constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_DERIV || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_ROWADD;
+    constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_ROWADD;
     f32x4 bias = {0.f, 0.f, 0.f, 0.f};
     if (HAS_BIAS && p.bias && n < p.N) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
@@ -213,24 +193,13 @@ __device__ __forceinline__ void store_tile_out_lds16(const GemmArgs& p, float* _
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
             }
-            if (EPI == EPI_BIAS_GELU_DERIV) {
-                if (p.aux_out) {
-                    f32x4 dv;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) dv[j] = gelu_erf_grad(v[j]);
-                    *reinterpret_cast<f32x4*>(p.aux_out + (long)m * p.ldc + n) = dv;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-            }
-            if (EPI == EPI_BIAS_RESID || EPI == EPI_MUL_GELU_GRAD || EPI == EPI_MUL_RELU_MASK || EPI == EPI_MUL_AUX) {
+            if (EPI == EPI_BIAS_RESID || EPI == EPI_MUL_GELU_GRAD || EPI == EPI_MUL_RELU_MASK) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + (long)m * p.ldaux + n);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (EPI == EPI_BIAS_RESID) v[j] += a[j];
                     if (EPI == EPI_MUL_GELU_GRAD) v[j] *= gelu_erf_grad(a[j]);
                     if (EPI == EPI_MUL_RELU_MASK) v[j] = a[j] > 0.f ? v[j] : 0.f;
-                    if (EPI == EPI_MUL_AUX) v[j] *= a[j];
                 }
             }
             if (EPI == EPI_BIAS_ROWADD) {
@@ -259,8 +228,6 @@ __device__ __forceinline__ void store_tile_dispatch_lds16(int epi, const GemmArg
         case EPI_MUL_RELU_MASK: store_tile_out_lds16<EPI_MUL_RELU_MASK, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
         case EPI_BIAS_ROWADD: store_tile_out_lds16<EPI_BIAS_ROWADD, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
         case EPI_ACCUM: store_tile_out_lds16<EPI_ACCUM, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
-        case EPI_BIAS_GELU_DERIV: store_tile_out_lds16<EPI_BIAS_GELU_DERIV, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
-        case EPI_MUL_AUX: store_tile_out_lds16<EPI_MUL_AUX, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
         default: store_tile_out_lds16<EPI_NONE, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
     }
 }
@@ -278,8 +245,6 @@ __device__ __forceinline__ void store_tile_dispatch_lds(int epi, const GemmArgs&
         case EPI_MUL_RELU_MASK: store_tile_out_lds<EPI_MUL_RELU_MASK, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
         case EPI_BIAS_ROWADD: store_tile_out_lds<EPI_BIAS_ROWADD, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
         case EPI_ACCUM: store_tile_out_lds<EPI_ACCUM, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
-        case EPI_BIAS_GELU_DERIV: store_tile_out_lds<EPI_BIAS_GELU_DERIV, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
-        case EPI_MUL_AUX: store_tile_out_lds<EPI_MUL_AUX, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
         default: store_tile_out_lds<EPI_NONE, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
     }
 }

@@ -291,8 +291,6 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 1) void gemm_f3
         case EPI_MUL_RELU_MASK: store_tile_out<EPI_MUL_RELU_MASK, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
         case EPI_BIAS_ROWADD: store_tile_out<EPI_BIAS_ROWADD, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
         case EPI_ACCUM: store_tile_out<EPI_ACCUM, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
-        case EPI_BIAS_GELU_DERIV: store_tile_out<EPI_BIAS_GELU_DERIV, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
-        case EPI_MUL_AUX: store_tile_out<EPI_MUL_AUX, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
         default: store_tile_out<EPI_NONE, MT, NT>(p, Cb, acc, mbase, nbase, half); break;
     }
 }
@@ -614,7 +612,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(GemmArgs p, cons
     float v = 0.f;
     for (int z = 0; z < slabs; ++z) v += ws[(long)z * slab_stride + idx];
     const int e = p.epi;
-    const bool has_bias = e == EPI_BIAS || e == EPI_BIAS_RELU || e == EPI_BIAS_GELU || e == EPI_BIAS_GELU_DERIV || e == EPI_BIAS_RESID || e == EPI_BIAS_ROWADD;
+    const bool has_bias = e == EPI_BIAS || e == EPI_BIAS_RELU || e == EPI_BIAS_GELU || e == EPI_BIAS_RESID || e == EPI_BIAS_ROWADD;
     if (has_bias && p.bias) v += p.bias[n];
     long orow = m;
     if (e == EPI_BIAS_ROWADD && p.remap_rows_per_img > 0) orow = (long)m + (long)(m / p.remap_rows_per_img) * p.remap_skip + p.remap_skip;
@@ -625,11 +623,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(GemmArgs p, cons
         v = gelu_erf(v);
     }
     if (e == EPI_BIAS_RESID) v += p.aux[(long)m * p.ldaux + n];
-    if (e == EPI_BIAS_GELU_DERIV) {
-        if (p.aux_out) p.aux_out[(long)m * p.ldc + n] = gelu_erf_grad(v);
-        v = gelu_erf(v);
-    }
-    if (e == EPI_MUL_AUX) v *= p.aux[(long)m * p.ldaux + n];
     if (e == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(p.aux[(long)m * p.ldaux + n]);
     if (e == EPI_MUL_RELU_MASK) v = p.aux[(long)m * p.ldaux + n] > 0.f ? v : 0.f;
     if (e == EPI_BIAS_ROWADD) v += p.aux[(long)(m % p.aux_rows) * p.ldaux + n];
@@ -929,7 +922,7 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
                      int remap_rows_per_img, int remap_skip, int accumulate, void* workspace, size_t workspace_bytes,
                      hipStream_t stream, float* colsum_out, int mode) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || layout < 0 || layout > 2 || mode < 0 || mode > 2) return D2S_ERR_ARG;
-    if ((epilogue == EPI_BIAS_RESID || epilogue == EPI_MUL_GELU_GRAD || epilogue == EPI_MUL_RELU_MASK || epilogue == EPI_MUL_AUX ||
+    if ((epilogue == EPI_BIAS_RESID || epilogue == EPI_MUL_GELU_GRAD || epilogue == EPI_MUL_RELU_MASK ||
          epilogue == EPI_BIAS_ROWADD) && !aux)
         return D2S_ERR_ARG;
     GemmArgs p;

@@ -346,8 +346,6 @@ __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, Piec
         case EPI_MUL_RELU_MASK: store_tile_out<EPI_MUL_RELU_MASK, 2, 2>(p, Cb, acc, mbase, nbase, half); break;
         case EPI_BIAS_ROWADD: store_tile_out<EPI_BIAS_ROWADD, 2, 2>(p, Cb, acc, mbase, nbase, half); break;
         case EPI_ACCUM: store_tile_out<EPI_ACCUM, 2, 2>(p, Cb, acc, mbase, nbase, half); break;
-        case EPI_BIAS_GELU_DERIV: store_tile_out<EPI_BIAS_GELU_DERIV, 2, 2>(p, Cb, acc, mbase, nbase, half); break;
-        case EPI_MUL_AUX: store_tile_out<EPI_MUL_AUX, 2, 2>(p, Cb, acc, mbase, nbase, half); break;
         default: store_tile_out<EPI_NONE, 2, 2>(p, Cb, acc, mbase, nbase, half); break;
     }
     }

@@ -160,9 +160,7 @@ class BlockFn(torch.autograd.Function):
         x1 = ops.linear_fwd(ao, projw, projb, epi=ops.EPI_BIAS_RESID, aux=x2d)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x1, cmap, n2w, n2b, M, D, eps)
         z = torch.empty((M, fc1w.shape[0]), dtype=torch.float32, device=x.device)
-        # z receives gelu'(pre-activation): formed in the forward epilogue, where the erf is computed anyway, so that the backward's
-        # epilogue is one multiply (EPI_MUL_AUX) instead of an erf + exp per element (31 us of the 169 us dgrad launch at n = 99)
-        h = ops.linear_fwd(ln2, fc1w, fc1b, epi=ops.EPI_BIAS_GELU_DERIV, aux_out=z)
+        h = ops.linear_fwd(ln2, fc1w, fc1b, epi=ops.EPI_BIAS_GELU, aux_out=z)
         y = ops.linear_fwd(h, fc2w, fc2b, epi=ops.EPI_BIAS_RESID, aux=x1)
         ctx.save_for_backward(x, n1w, qkvw, projw, n2w, fc1w, fc2w, mean1, rstd1, ln1, qkv, ao, lse, x1, mean2, rstd2, ln2, z, h,
                               n1b, qkvb, projb, n2b, fc1b, fc2b)
@@ -190,7 +188,7 @@ class BlockFn(torch.autograd.Function):
 
         # ---- MLP branch ----
         grads[11], grads[12] = ops.linear_param_grads(gy, h, fc2w, fc2b, wants[11], wants[12])
-        dz = ops.linear_dgrad(gy, fc2w, epi=ops.EPI_MUL_AUX, aux=z)
+        dz = ops.linear_dgrad(gy, fc2w, epi=ops.EPI_MUL_GELU_GRAD, aux=z)
         grads[9], grads[10] = ops.linear_param_grads(dz, ln2, fc1w, fc1b, wants[9], wants[10])
         dln2 = ops.linear_dgrad(dz, fc1w)
         g1 = torch.empty((M, D), dtype=torch.float32, device=dev)

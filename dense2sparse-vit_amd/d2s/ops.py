@@ -11,7 +11,6 @@ from . import lib
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_GELU, EPI_BIAS_RESID = 0, 1, 2, 3, 4
 EPI_MUL_GELU_GRAD, EPI_MUL_RELU_MASK, EPI_BIAS_ROWADD, EPI_ACCUM = 5, 6, 7, 8
-EPI_BIAS_GELU_DERIV, EPI_MUL_AUX = 9, 10
 NT, NN, TN = 0, 1, 2
 
 _ws = {}

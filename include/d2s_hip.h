@@ -36,9 +36,7 @@ typedef struct ihipStream_t* d2s_stream_t; /* == hipStream_t */
  * layout 0 "NT": C[M,N] = A[M,K] * B[N,K]^T (forward); 1 "NN": C[M,N] = A[M,K] * B[K,N] (dgrad);
  * layout 2 "TN": C[M,N] = A[K,M]^T * B[K,N] (wgrad; split-K slabs in `workspace`, deterministic combine).
  * epilogue: 0 none, 1 +bias[n], 2 relu(+bias), 3 gelu(+bias) with pre-activation copy to aux_out, 4 +bias+aux[m][n],
- *           5 *gelu'(aux[m][n]), 6 *(aux[m][n] > 0), 7 +bias+aux[m % aux_rows][n] (pos_embed add), 8 C += acc,
- *           9 gelu(+bias) with gelu'(pre-activation) written to aux_out (Mlp forward of a training step: the backward's epilogue
- *           becomes kind 10), 10 *aux[m][n].
+ *           5 *gelu'(aux[m][n]), 6 *(aux[m][n] > 0), 7 +bias+aux[m % aux_rows][n] (pos_embed add), 8 C += acc.
  * remap_rows_per_img/remap_skip: output row m goes to m + (m / rows_per_img + 1) * skip (leave room for CLS rows). */
 /* GEMM arithmetic mode (NT / NN layouts in modes 1 and 2; the weight gradient follows in mode 2 only, its bias gradient stays an
  * exact fp32 column sum): 0 = exact fp32 MFMA; 1 = "bf16x3 split":
