@@ -317,7 +317,9 @@ class TrainStep:
             student.grad_ready_hook = lambda i: self.reducer.ready_from(self.block_offset[i])
         self.frozen = frozenset(n for n, p in student.named_parameters() if not p.requires_grad)
         import os
-        two = os.environ.get("D2S_TEACHER_STREAM", "0") == "1" and self.arena.params.is_cuda
+        # the frozen teacher's forward runs on a second HIP stream beside the student's forward (independent until the losses):
+        # +2.6 % images/s, identical losses (profiles/r02_f_teacher_stream_ab.txt).  D2S_TEACHER_STREAM=0 serialises them.
+        two = os.environ.get("D2S_TEACHER_STREAM", "1") == "1" and self.arena.params.is_cuda
         self._teacher_stream = torch.cuda.Stream() if two else None
         self.set_epoch(0)
 
@@ -339,12 +341,19 @@ class TrainStep:
             # The frozen teacher's forward and the student's forward are independent until the losses: the teacher runs on a second
             # HIP stream so that its kernels fill the CUs the student's kernels leave idle in their ramp-up / last residency round
             # (and vice versa).  Scratch buffers are per stream (ops.workspace), so the two forwards never share one.
+            from .functional import shared_patch_columns, prime_patch_columns
             side, main = self._teacher_stream, torch.cuda.current_stream()
-            side.wait_stream(main)
-            with torch.cuda.stream(side), torch.no_grad():
-                logits_t, token_t, cls_attn = self.teacher(images)
-            logits_s, token_s, pred_logits, kept = self.student(images)
-            main.wait_stream(side)
+            with shared_patch_columns():
+                pe = getattr(self.student, "patch_embed", None)
+                if pe is not None and images.is_contiguous() and hasattr(pe, "patch_size") and getattr(self.teacher, "patch_embed", None) is not None:
+                    prime_patch_columns(images, pe.patch_size[0])       # one im2col for both, built before the fork
+                side.wait_stream(main)
+                with torch.cuda.stream(side), torch.no_grad():
+                    logits_t, token_t, cls_attn = self.teacher(images)
+                logits_s, token_s, pred_logits, kept = self.student(images)
+                main.wait_stream(side)
+            for t in (logits_t, token_t, cls_attn):      # produced on the side stream, consumed (and later freed) on the main one
+                t.record_stream(main)
         else:
             from .functional import shared_patch_columns
             with shared_patch_columns():       # teacher and student embed the same images: one im2col pass for both

@@ -66,11 +66,20 @@ def _patch_columns(img, patch):
         return ops.im2col_patch(img, patch)
     stream = torch.cuda.current_stream(img.device).cuda_stream
     ent = _COLS["entry"]
-    if ent is not None and ent[0]() is img and ent[1:4] == (img._version, patch, stream):
+    if ent is not None and ent[0]() is img and ent[1:3] == (img._version, patch) and ent[3] in (stream, None):
         return ent[4]
     col = ops.im2col_patch(img, patch)
     _COLS["entry"] = (weakref.ref(img), img._version, patch, stream, col)
     return col
+
+
+def prime_patch_columns(img, patch):
+    """Build the im2col matrix of `img` now, on the current stream, and mark it usable from ANY stream: for a caller that then forks
+    work onto a second stream which first waits on this one (d2s.engine.TrainStep with the teacher on its own stream)."""
+    if _COLS["depth"] == 0:
+        return
+    img = img.contiguous()
+    _COLS["entry"] = (weakref.ref(img), img._version, patch, None, ops.im2col_patch(img, patch))
 
 
 @mode_recorded

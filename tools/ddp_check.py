@@ -47,6 +47,10 @@ def main():
     own_gpu = ngpu >= world
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if own_gpu else 0)
     torch.cuda.set_device(dev)
+    if os.environ.get("D2S_FORCE_NCCL") == "1":      # rehearsal: RCCL with every rank on the same GPU (if the library allows it)
+        own_gpu = True
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
     dist.init_process_group("nccl" if own_gpu else "gloo", rank=rank, world_size=world)
     case = dict(cases.MODEL_CASES["micro2"])
     per = 2
