@@ -383,6 +383,7 @@ def main():
         # in series with the student's (the timed region above overlaps them on two streams)
         two_streams = getattr(ts, "_teacher_stream", None)
         ts._teacher_stream = None
+        wgrad_async, ops._WGRAD_ENABLED = ops._WGRAD_ENABLED, False      # ... and the weight gradients on the main stream
         t1 = time.perf_counter()
         for _ in range(args.steps):
             ts(images, labels)
@@ -393,6 +394,7 @@ def main():
         instr_elapsed = time.perf_counter() - t1
         timer.enabled = False
         ts._teacher_stream = two_streams
+        ops._WGRAD_ENABLED = wgrad_async
         log(f"instrumented pass done: {args.steps} steps in {instr_elapsed:.3f} s")
 
     if distributed:
@@ -423,8 +425,8 @@ def main():
             line["kernel_timing"] = {"method": "HIP events around every GEMM / gather / scatter / LayerNorm / AdamW launch on the launch stream, "
                                                + ("inside the timed region" if in_region else
                                                   "in a second pass of the same K steps after the timed region (the events cost ~5 % of the step), with the teacher's forward "
-                                                  "in series with the student's - the timed region overlaps them on two HIP streams, where per-kernel durations would read "
-                                                  "low because kernels share the GPU"),
+                                                  "in series with the student's and the weight-gradient GEMMs in series with the rest of backward - the timed region "
+                                                  "overlaps both pairs on separate HIP streams, where per-kernel durations would read low because kernels share the GPU"),
                                      "instrumented_ms_per_step": round(1000.0 * instr_elapsed / args.steps, 3)}
         gemms = {k: v for k, v in summ.items() if k[0] == "gemm_f32"}
         if gemms:

@@ -241,6 +241,9 @@ class GradReducer:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
             return
         self.stream.wait_stream(torch.cuda.current_stream())
+        wg = ops.weight_grad_stream()
+        if wg is not None:                          # the weight gradients of this bucket were written on their own stream
+            self.stream.wait_stream(wg)
         with torch.cuda.stream(self.stream):
             if self.timing:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -372,7 +375,8 @@ class TrainStep:
         self.student.train()
         loss, info = self.forward_losses(images, labels)
         self.opt.zero_grad()
-        loss.backward()
+        with ops.async_weight_grads():              # wgrad GEMMs trail the dgrad chain on a second stream; joined on exit
+            loss.backward()
         self.arena.collect_grads()
         scale = self.reducer.finish() if self.reducer is not None else 1.0
         self.opt.step(grad_scale=scale)

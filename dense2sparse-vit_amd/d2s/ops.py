@@ -164,14 +164,67 @@ def linear_wgrad(dy, x, dW, accumulate=False, db=None):
     return dW
 
 
+# ---- weight gradients on their own stream ----
+# Within a backward pass nothing waits for a weight gradient: dW / db of a Linear are only read by the optimiser (and the gradient
+# all-reduce), while the chain that the next layer waits for is dy -> dx.  Inside `async_weight_grads()` (d2s.engine.TrainStep wraps its
+# backward in it) the wgrad GEMMs, their slab combines and the bias column sums are issued on a second HIP stream that trails the main
+# one, so they fill the CUs that the dgrad / attention kernels of the following layers leave idle in their tails; the caller joins the
+# stream before anything reads the gradients (join_weight_grads).  Outside that block - any caller that runs loss.backward() itself and
+# then reads .grad on the current stream - everything stays on the current stream.
+_WGRAD = {"on": False, "stream": None, "used": False}
+_WGRAD_ENABLED = os.environ.get("D2S_WGRAD_STREAM", "1") != "0"
+
+
+class async_weight_grads:
+    def __enter__(self):
+        if _WGRAD_ENABLED and torch.cuda.is_available():
+            if _WGRAD["stream"] is None:
+                _WGRAD["stream"] = torch.cuda.Stream()
+            _WGRAD["on"], _WGRAD["used"] = True, False
+        return self
+
+    def __exit__(self, *exc):
+        _WGRAD["on"] = False
+        join_weight_grads()
+        return False
+
+
+def weight_grad_stream():
+    """The side stream if weight gradients were issued on it since the last join, else None (the reducer of the data-parallel path
+    makes its own stream wait on it before it all-reduces a bucket)."""
+    return _WGRAD["stream"] if _WGRAD["used"] else None
+
+
+def join_weight_grads():
+    if _WGRAD["used"] and _WGRAD["stream"] is not None:
+        torch.cuda.current_stream().wait_stream(_WGRAD["stream"])
+    _WGRAD["used"] = False
+
+
 def linear_param_grads(dy, x, W, b, want_w=True, want_b=True, accumulate=False):
     """(dW, db) of a Linear into fresh arena-backed buffers: one fused pass when both are wanted."""
     dW = grad_buffer(W) if want_w else None
     db = grad_buffer(b) if (want_b and b is not None) else None
-    if dW is not None:
-        linear_wgrad(dy, x, dW, accumulate=accumulate, db=db)
-    elif db is not None:
-        colsum(dy, db, accumulate=accumulate)
+    if dW is None and db is None:
+        return dW, db
+    side = _WGRAD["stream"] if (_WGRAD["on"] and dy.is_cuda) else None
+    if side is None:
+        if dW is not None:
+            linear_wgrad(dy, x, dW, accumulate=accumulate, db=db)
+        else:
+            colsum(dy, db, accumulate=accumulate)
+        return dW, db
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)                       # dy (and x) were produced on the main stream
+    with torch.cuda.stream(side):
+        if dW is not None:
+            linear_wgrad(dy, x, dW, accumulate=accumulate, db=db)
+        else:
+            colsum(dy, db, accumulate=accumulate)
+    for t in (dy, x, dW, db):                    # autograd may free these on the main stream while the side stream still reads / writes them
+        if t is not None:
+            t.record_stream(side)
+    _WGRAD["used"] = True
     return dW, db
 
 
