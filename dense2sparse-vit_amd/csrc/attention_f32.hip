@@ -509,6 +509,25 @@ int d2s_attn_bwd_f32(const float* qkv, const float* out, const float* dout, cons
     return d2s_check_launch();
 }
 
+// The two halves of d2s_attn_bwd_f32 as separate entry points (delta_ws from d2s_attn_delta): dQ and dK/dV write disjoint thirds of
+// dqkv and do not depend on each other, so a caller may issue them on two streams and let them share the GPU.
+int d2s_attn_bwd_dq_f32(const float* qkv, const float* dout, const float* lse, const float* delta_ws, float* dqkv, int B, int n, int H,
+                        float scale, hipStream_t stream) {
+    if (!qkv || !dout || !lse || !dqkv || !delta_ws || B <= 0 || n <= 0 || H <= 0) return D2S_ERR_ARG;
+    dim3 grid((n + 127) / 128, B * H), block(256);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, n, H, scale,
+                       static_cast<const float*>(nullptr));
+    return d2s_check_launch();
+}
+int d2s_attn_bwd_dkv_f32(const float* qkv, const float* dout, const float* lse, const float* delta_ws, float* dqkv, int B, int n, int H,
+                         float scale, hipStream_t stream) {
+    if (!qkv || !dout || !lse || !dqkv || !delta_ws || B <= 0 || n <= 0 || H <= 0) return D2S_ERR_ARG;
+    dim3 grid((n + 127) / 128, B * H), block(256);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, n, H, scale,
+                       static_cast<const float*>(nullptr), static_cast<const float*>(nullptr));
+    return d2s_check_launch();
+}
+
 // Backward of d2s_attn_policy_fwd_f32 (lse, cinv as that call wrote them).
 int d2s_attn_policy_bwd_f32(const float* qkv, const float* policy, const float* out, const float* dout, const float* lse,
                             const float* cinv, float* dqkv, float* delta_ws, int B, int n, int H, float scale, hipStream_t stream) {

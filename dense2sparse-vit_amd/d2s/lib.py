@@ -52,6 +52,8 @@ _SIGS = {
     "d2s_attn_bwd_f32": (I, [P, P, P, P, P, P, I, I, I, F]),
     "d2s_attn_bwd_bf16": (I, [P, P, P, P, P, P, I, I, I, F]),
     "d2s_attn_delta": (I, [P, P, P, I, I, I]),
+    "d2s_attn_bwd_dq_f32": (I, [P, P, P, P, P, I, I, I, F]),
+    "d2s_attn_bwd_dkv_f32": (I, [P, P, P, P, P, I, I, I, F]),
     "d2s_teacher_target": (I, [P, P, I, I, I, I]),
     "d2s_gather_renorm": (I, [P, P, P, I, I, I, I]),
     "d2s_kl_rows": (I, [P, L, L, L, L, P, L, L, L, L, P, P, P, P, L, I, I, P]),

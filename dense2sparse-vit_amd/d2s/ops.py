@@ -173,6 +173,8 @@ def linear_wgrad(dy, x, dW, accumulate=False, db=None):
 # then reads .grad on the current stream - everything stays on the current stream.
 _WGRAD = {"on": False, "stream": None, "used": False}
 _WGRAD_ENABLED = os.environ.get("D2S_WGRAD_STREAM", "1") != "0"
+_ATTN_BWD_STREAMS = os.environ.get("D2S_ATTN_BWD_STREAMS", "0") == "1"      # dQ and dK/dV kernels of the attention backward side by side:
+# measured +-0 on top of the weight-gradient stream (3503 / 3502 images/s), so off by default
 
 
 class async_weight_grads:
@@ -407,7 +409,21 @@ def attn_fwd(qkv, B, n, H, scale, want_cls=True):
 def attn_bwd(qkv, out, dout, lse, B, n, H, scale):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device)
-    entry = "d2s_attn_bwd_bf16" if (get_gemm_mode() == GEMM_BF16 and _BF16_ATTENTION) else "d2s_attn_bwd_f32"
+    bf16 = get_gemm_mode() == GEMM_BF16 and _BF16_ATTENTION
+    if _WGRAD["on"] and _ATTN_BWD_STREAMS and not bf16 and qkv.is_cuda:
+        # inside TrainStep's backward: the dK/dV kernel on a stream of its own beside the dQ kernel (independent, disjoint outputs);
+        # both are joined again before anything reads dqkv
+        if _WGRAD.get("attn_stream") is None:
+            _WGRAD["attn_stream"] = torch.cuda.Stream()
+        side, main = _WGRAD["attn_stream"], torch.cuda.current_stream()
+        lib.call("d2s_attn_delta", lib.ptr(out), lib.ptr(dout), lib.ptr(delta), B, n, H)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            lib.call("d2s_attn_bwd_dkv_f32", lib.ptr(qkv), lib.ptr(dout), lib.ptr(lse), lib.ptr(delta), lib.ptr(dqkv), B, n, H, float(scale))
+        lib.call("d2s_attn_bwd_dq_f32", lib.ptr(qkv), lib.ptr(dout), lib.ptr(lse), lib.ptr(delta), lib.ptr(dqkv), B, n, H, float(scale))
+        main.wait_stream(side)
+        return dqkv
+    entry = "d2s_attn_bwd_bf16" if bf16 else "d2s_attn_bwd_f32"
     lib.call(entry, lib.ptr(qkv), lib.ptr(out), lib.ptr(dout), lib.ptr(lse), lib.ptr(dqkv), lib.ptr(delta), B, n, H, float(scale))
     return dqkv
 

@@ -87,6 +87,12 @@ int d2s_attn_fwd_bf16(const float* qkv, float* out, float* lse, float* cls_row, 
                       d2s_stream_t stream);
 int d2s_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws,
                      int B, int n, int H, float scale, d2s_stream_t stream);
+/* the two independent halves of d2s_attn_bwd_f32 (delta_ws [B,H,n] from d2s_attn_delta): dQ, and dK / dV; they write disjoint parts of
+ * dqkv, so they may run concurrently on two streams */
+int d2s_attn_bwd_dq_f32(const float* qkv, const float* dout, const float* lse, const float* delta_ws, float* dqkv, int B, int n, int H,
+                        float scale, d2s_stream_t stream);
+int d2s_attn_bwd_dkv_f32(const float* qkv, const float* dout, const float* lse, const float* delta_ws, float* dqkv, int B, int n, int H,
+                         float scale, d2s_stream_t stream);
 /* delta[b,h,i] = sum_d dout * out (row term of the softmax backward); the two backward entries call it themselves */
 int d2s_attn_delta(const float* out, const float* dout, float* delta, int B, int n, int H, d2s_stream_t stream);
 /* backward on the bf16 matrix cores (bf16 arithmetic mode), same contract as d2s_attn_bwd_f32 */
