@@ -836,9 +836,12 @@ size_t split_tn_pieces_bytes(int split, int M, int N, int K);
 int split_tn_colsum_partials(int K);
 int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_ws, float* colsum_part, hipStream_t stream);
 }
-// Workgroups the wgrad launch aims for (tiles x K slices, rounded down): exactly 2 per CU.  Measured on the model's shapes
-// (tools/gemm_bench.py, D2S_SPLITK_TARGET sweep): 512 beats 768 / 1024 by 4-15 % (fewer, longer K slices: less slab traffic for the
-// ordered combine), and any count that is not a multiple of the CU count loses 10-40 % to imbalance.
+// Workgroups the wgrad launch aims for (tiles x K slices, rounded down).  Run alone, exactly 2 per CU is best (tools/gemm_bench.py,
+// D2S_SPLITK_TARGET sweep in round 1: 512 beats 768 / 1024 by 4-15 % - fewer, longer K slices mean less slab traffic for the ordered
+// combine - and any count that is not a multiple of the CU count loses 10-40 % to imbalance).  Inside the training step the weight
+// gradients run on their own stream BESIDE the dgrad / attention kernels (d2s.ops.async_weight_grads), where shorter workgroups interleave
+// better: 3 per CU measured best there (step: 256 -> 3483, 384 -> 3470, 512 -> 3513, 768 -> 3556, 1024 -> 3526, 1536 -> 3508, 2048 -> 3490
+// images/s on one box), so that is the default.
 static int splitk_target() {
     static const int t = [] {
         const char* e = getenv("D2S_SPLITK_TARGET");
@@ -846,7 +849,7 @@ static int splitk_target() {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
-        return 2 * cus;
+        return 3 * cus;
     }();
     return t;
 }
