@@ -14,13 +14,14 @@ EPI_MUL_GELU_GRAD, EPI_MUL_RELU_MASK, EPI_BIAS_ROWADD, EPI_ACCUM = 5, 6, 7, 8
 NT, NN, TN = 0, 1, 2
 
 _ws = {}
+_WS_NEED = {}       # (layout, M, N, K, mode) -> workspace bytes of d2s_gemm_f32 (a pure function of its arguments)
 _BF16_ATTENTION = os.environ.get("D2S_BF16_ATTENTION", "1") != "0"
 
 
 def workspace(nbytes, device):
     """Grow-only scratch buffer per (device, stream): kernels of one stream reuse it in order, kernels of different streams (the
     optional teacher stream, d2s.engine) never share one."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    key = (device.type, device.index, lib.stream() if device.type == "cuda" else 0)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -36,7 +37,10 @@ def _f32(t):
 def gemm(layout, A, lda, B, ldb, C, ldc, M, N, K, epi=EPI_NONE, bias=None, aux=None, ldaux=0, aux_out=None, aux_rows=0,
          remap_rows=0, remap_skip=0, accumulate=False):
     mode = get_gemm_mode()
-    need = lib.query("d2s_gemm_f32_workspace_bytes", layout, M, N, K, mode)
+    qk = (layout, M, N, K, mode)
+    need = _WS_NEED.get(qk)
+    if need is None:
+        need = _WS_NEED[qk] = lib.query("d2s_gemm_f32_workspace_bytes", layout, M, N, K, mode)
     ws = workspace(need, C.device) if need else None
     lib.call("d2s_gemm_f32", layout, lib.ptr(A), lda, lib.ptr(B), ldb, lib.ptr(C), ldc, M, N, K, epi, lib.ptr(bias),
              lib.ptr(aux), ldaux, lib.ptr(aux_out), aux_rows, remap_rows, remap_skip, int(accumulate), mode, lib.ptr(ws),
