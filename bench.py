@@ -60,6 +60,9 @@ def parse():
                     help="c5 only: keep int(196 * ratio) = 58 tokens of the 576 (the reference hard-codes init_n = 14*14, dynamic_vit.py:828,852) "
                          "instead of int(576 * ratio) = 172")
     ap.add_argument("--gemm-shapes-out", default=None, help="write the in-step per-shape GEMM times (layout M N K launches us TFLOP/s) to this file")
+    ap.add_argument("--serial", action="store_true",
+                    help="issue every kernel on one stream also in the timed region (no teacher / weight-gradient stream overlap): the form in which "
+                         "per-kernel durations are meaningful - used for the rocprofv3 kernel-stats profile that has to agree with roofline.avg_launch_us")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented pass (no per-kernel figures in the line)")
     ap.add_argument("--time-kernels-in-region", action="store_true",
@@ -341,6 +344,9 @@ def main():
     targs = types.SimpleNamespace(keep_ratios=list(args.keeps), mask_loss_type="kl_div", mixup=0.0, patch_score_threshold=None, step=0)
     ts = TrainStep(student, teacher, targs, lr=5e-4, min_lr=1e-5, weight_decay=0.05, epochs=25, warmup_steps=0,
                    distributed=distributed)
+    if args.serial:
+        ts._teacher_stream = None
+        ops._WGRAD_ENABLED = False
     if distributed:
         ts.reducer.force = force_dist
         dist.broadcast(ts.arena.params, src=0)
