@@ -75,6 +75,65 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
+// D = 384 (every DeiT-S block LayerNorm): a row is 96 float4, i.e. 1.5 per lane - half the wave idles on the second load.  Two rows
+// per wave are 192 float4 = 3 per lane, all lanes busy and 3 loads in flight per lane.  Lane l holds vectors c = l, 64 + l, 128 + l of the
+// concatenated pair; c < 96 belongs to the first row.  The reductions are segmented (one sum per row), same count as before.
+__global__ __launch_bounds__(256) void ln_fwd_pair96_kernel(const float* __restrict__ x, RowMap xm, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            long rows, float eps) {
+    constexpr int NVEC = 96, D = 384;
+    const int lane = threadIdx.x & 63;
+    const long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long r0 = pair * 2;
+    if (r0 >= rows) return;
+    const bool has1 = r0 + 1 < rows;
+    const float* xr0 = x + map_row(xm, r0);
+    const float* xr1 = has1 ? x + map_row(xm, r0 + 1) : xr0;
+    f32x4 v[3];
+    int col[3];
+    bool second[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = lane + 64 * i;
+        second[i] = c >= NVEC;
+        col[i] = second[i] ? c - NVEC : c;
+        v[i] = *reinterpret_cast<const f32x4*>((second[i] ? xr1 : xr0) + col[i] * 4);
+    }
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float t = (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        if (second[i]) s1 += t; else s0 += t;
+    }
+    const float mean0 = wave_sum(s0) / (float)D, mean1 = wave_sum(s1) / (float)D;
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float m = second[i] ? mean1 : mean0;
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - m; t += d * d; }
+        if (second[i]) q1 += t; else q0 += t;
+    }
+    const float rstd0 = 1.0f / sqrtf(wave_sum(q0) / (float)D + eps), rstd1 = 1.0f / sqrtf(wave_sum(q1) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (second[i] && !has1) continue;
+        const float m = second[i] ? mean1 : mean0, r = second[i] ? rstd1 : rstd0;
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + col[i] * 4);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b + col[i] * 4);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - m) * r * wv[j] + bv[j];
+        *reinterpret_cast<f32x4*>(y + (r0 + (second[i] ? 1 : 0)) * D + col[i] * 4) = o;
+    }
+    if (lane == 0) {
+        if (mean_out) { mean_out[r0] = mean0; if (has1) mean_out[r0 + 1] = mean1; }
+        if (rstd_out) { rstd_out[r0] = rstd0; if (has1) rstd_out[r0 + 1] = rstd1; }
+    }
+}
+
 // Backward.  Each block owns a contiguous chunk of rows; every wave walks its share and accumulates dweight /
 // dbias in registers; partials land in part[block][2][D].
 template <int NV>
@@ -335,6 +394,11 @@ int d2s_layernorm_fwd(const float* x, long rows_per_group, long group_stride, lo
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     if ((D & 3) || ((group_stride | row_stride | offset) & 3)) {
         hipLaunchKernelGGL(ln_fwd_scalar_kernel, grid, block, 0, stream, x, m, w, b, y, mean, rstd, rows, D, eps);
+        return d2s_check_launch();
+    }
+    static const int pair_env = [] { const char* e = getenv("D2S_LN_PAIR"); return e ? atoi(e) : 1; }();
+    if (D == 384 && pair_env) {
+        hipLaunchKernelGGL(ln_fwd_pair96_kernel, dim3((unsigned)((rows + 7) / 8)), block, 0, stream, x, m, w, b, y, mean, rstd, rows, eps);
         return d2s_check_launch();
     }
     switch (pick_nv(D)) {
