@@ -3,6 +3,7 @@
 # configs and arithmetic modes on one GPU.  usage: tools/evidence_round.sh <tag>
 TAG=$1
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+cd $ROOT && python -c "import __graft_entry__ as g; g.smoke()" || exit 1
 cd $ROOT && bash tools/gpu_round.sh $TAG || exit 1
 bash tools/pmc_traffic.sh ${TAG} || exit 1
 cd $ROOT
