@@ -492,6 +492,9 @@ def main():
                                 "frac": round(gbs / PEAK_HBM_GBS, 4), "launches_per_step": rec["launches"] / args.steps,
                                 "ms_per_step": round(rec["ms"] / args.steps, 3)}
         line["hbm_copy_GBps_measured"] = hbm_copy_gbs(device)
+        # the same device-to-device copy at the size of ONE gather / LayerNorm launch of this workload (19.5 MB read + 19.5 MB written):
+        # what a 39 MB transfer can reach at all, launch ramp included - the yardstick for the in-step gather / scatter / LayerNorm rates
+        line["hbm_copy_GBps_at_39MB"] = hbm_copy_gbs(device, mbytes=19, reps=50)
         if distributed:
             c = ts.reducer.comm_summary(args.steps * (2 if (instr_elapsed is not None and not in_region) else 1))   # both passes all-reduce
             if c:
