@@ -29,7 +29,7 @@ __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, co
 }
 
 __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                               float* __restrict__ lse, float* __restrict__ cls_row, int n, int H,
+                                                               __bf16* __restrict__ out16, float* __restrict__ lse, float* __restrict__ cls_row, int n, int H,
                                                                float scale) {
     __shared__ __attribute__((aligned(16))) __bf16 Ks[32 * KP];      // [key][d]
     __shared__ __attribute__((aligned(16))) __bf16 Vt[DH * VP];      // [d][pos(key)]
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const float* __re
     const bool qok = q0 + l31 < n;
     const float inv_l = 1.0f / l_run;
     if (qok) {
-        float* p = out + ((long)b * n + q0 + l31) * H * DH + h * DH;
+        const long po = ((long)b * n + q0 + l31) * H * DH + h * DH;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -155,7 +155,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const float* __re
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = o[dt][4 * g + j] * inv_l;
-                *reinterpret_cast<f32x4*>(p + 32 * dt + 8 * g + 4 * half) = v;
+                if (out) *reinterpret_cast<f32x4*>(out + po + 32 * dt + 8 * g + 4 * half) = v;
+                if (out16) {      // bf16 copy for the projection GEMM of the bf16 mode (its a_bf16)
+                    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                    bf16x4_t hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hv[j] = (__bf16)v[j];
+                    *reinterpret_cast<bf16x4_t*>(out16 + po + 32 * dt + 8 * g + 4 * half) = hv;
+                }
             }
         if (half == 0) lse[((long)b * H + h) * n + q0 + l31] = m_run + logf(l_run);
     }
@@ -368,8 +375,19 @@ int d2s_attn_fwd_bf16(const float* qkv, float* out, float* lse, float* cls_row, 
                       hipStream_t stream) {
     if (!qkv || !out || !lse || B <= 0 || n <= 0 || H <= 0 || n > 8192) return D2S_ERR_ARG;
     dim3 grid((n + 127) / 128, B * H), block(256);
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, block, cls_row ? (size_t)n * sizeof(float) : 0, stream, qkv, out, lse, cls_row, n, H,
-                       scale);
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, block, cls_row ? (size_t)n * sizeof(float) : 0, stream, qkv, out,
+                       static_cast<__bf16*>(nullptr), lse, cls_row, n, H, scale);
+    return d2s_check_launch();
+}
+
+// The same forward with a dense [B, n, H*64] bf16 copy of the output (the a_bf16 of the projection GEMM); out may be NULL in forward-only
+// passes that consume the bf16 form alone.
+int d2s_attn_fwd_bf16_bf16out(const float* qkv, float* out, void* out_bf16, float* lse, float* cls_row, int B, int n, int H, float scale,
+                              hipStream_t stream) {
+    if (!qkv || !out_bf16 || !lse || B <= 0 || n <= 0 || H <= 0 || n > 8192) return D2S_ERR_ARG;
+    dim3 grid((n + 127) / 128, B * H), block(256);
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, block, cls_row ? (size_t)n * sizeof(float) : 0, stream, qkv, out,
+                       static_cast<__bf16*>(out_bf16), lse, cls_row, n, H, scale);
     return d2s_check_launch();
 }
 

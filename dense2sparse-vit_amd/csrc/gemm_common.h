@@ -33,6 +33,9 @@ struct GemmArgs {
     int vec_epilogue;  // 16-byte LDS-staged epilogue allowed (see epilogue_vec_ok)
     float* colsum;     // TN only: column sums of the A operand (bias gradient), one slab of M floats per K slice; may be null
     int colsum_accumulate;
+    // bf16 mode only (d2s_gemm_f32_bf16io): a16 = the A operand already rounded to bf16, dense [M][K] (K % 32 == 0) - no conversion pass;
+    // c16 = where to put a bf16 copy of the result, dense [M][N] (N % 32 == 0): the next GEMM's a16
+    const void* a16; void* c16;
 };
 
 template <int EPI, int MT, int NT>
@@ -82,7 +85,7 @@ __device__ __forceinline__ void store_tile_out(const GemmArgs& p, float* __restr
 // the main loop no longer uses (callers barrier after their last LDS read).
 __host__ __device__ constexpr int epi_stage_floats(int NT) { return 16 * (NT * 32 + 4); }
 
-template <int EPI, int MT, int NT>
+template <int EPI, int MT, int NT, bool C16 = false>
 __device__ __forceinline__ void store_tile_out_lds(const GemmArgs& p, float* __restrict__ Cb, const f32x16 (&acc)[MT][NT], int mrow0,
                                                    int ncol0, int lane, float* __restrict__ stage_wave) {
     constexpr int WN = NT * 32, PITCH = WN + 4, LPR = WN / 4, RPI = 64 / LPR, ITERS = 16 / RPI;
@@ -144,7 +147,16 @@ __device__ __forceinline__ void store_tile_out_lds(const GemmArgs& p, float* __r
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] += o[j];
                 }
-                *reinterpret_cast<f32x4*>(cp) = v;
+                if (!C16 || Cb) *reinterpret_cast<f32x4*>(cp) = v;
+                if constexpr (C16) {
+                    if (p.c16) {
+                        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                        bf16x4_t h;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) h[j] = (__bf16)v[j];
+                        *reinterpret_cast<bf16x4_t*>(static_cast<__bf16*>(p.c16) + orow * p.N + n) = h;
+                    }
+                }
             }
         }
     }
@@ -233,19 +245,19 @@ __device__ __forceinline__ void store_tile_dispatch_lds16(int epi, const GemmArg
 }
 
 // resolve the (wave-uniform) epilogue kind once; each kind has its own straight-line store loop
-template <int MT, int NT>
+template <int MT, int NT, bool C16 = false>
 __device__ __forceinline__ void store_tile_dispatch_lds(int epi, const GemmArgs& p, float* Cb, const f32x16 (&acc)[MT][NT], int mr, int nc,
                                                         int lane, float* stage) {
     switch (epi) {
-        case EPI_BIAS: store_tile_out_lds<EPI_BIAS, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
-        case EPI_BIAS_RELU: store_tile_out_lds<EPI_BIAS_RELU, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
-        case EPI_BIAS_GELU: store_tile_out_lds<EPI_BIAS_GELU, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
-        case EPI_BIAS_RESID: store_tile_out_lds<EPI_BIAS_RESID, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
-        case EPI_MUL_GELU_GRAD: store_tile_out_lds<EPI_MUL_GELU_GRAD, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
-        case EPI_MUL_RELU_MASK: store_tile_out_lds<EPI_MUL_RELU_MASK, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
-        case EPI_BIAS_ROWADD: store_tile_out_lds<EPI_BIAS_ROWADD, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
-        case EPI_ACCUM: store_tile_out_lds<EPI_ACCUM, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
-        default: store_tile_out_lds<EPI_NONE, MT, NT>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_BIAS: store_tile_out_lds<EPI_BIAS, MT, NT, C16>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_BIAS_RELU: store_tile_out_lds<EPI_BIAS_RELU, MT, NT, C16>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_BIAS_GELU: store_tile_out_lds<EPI_BIAS_GELU, MT, NT, C16>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_BIAS_RESID: store_tile_out_lds<EPI_BIAS_RESID, MT, NT, C16>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_MUL_GELU_GRAD: store_tile_out_lds<EPI_MUL_GELU_GRAD, MT, NT, C16>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_MUL_RELU_MASK: store_tile_out_lds<EPI_MUL_RELU_MASK, MT, NT, C16>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_BIAS_ROWADD: store_tile_out_lds<EPI_BIAS_ROWADD, MT, NT, C16>(p, Cb, acc, mr, nc, lane, stage); break;
+        case EPI_ACCUM: store_tile_out_lds<EPI_ACCUM, MT, NT, C16>(p, Cb, acc, mr, nc, lane, stage); break;
+        default: store_tile_out_lds<EPI_NONE, MT, NT, C16>(p, Cb, acc, mr, nc, lane, stage); break;
     }
 }
 

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, Piec
     float* Cb = p.C + (long)blockIdx.z * p.slab_stride;
     if (p.vec_epilogue) {   // LDS is free after the loop's final barrier; each wave uses its own staging buffer
         float* stage = reinterpret_cast<float*>(smem_raw) + wave * epi_stage_floats(2);
-        store_tile_dispatch_lds<2, 2>(p.epi, p, Cb, acc, row0 + wm * 64, col0 + wn * 64, lane, stage);
+        store_tile_dispatch_lds<2, 2, true>(p.epi, p, Cb, acc, row0 + wm * 64, col0 + wn * 64, lane, stage);
     } else {
     const int mbase = row0 + wm * 64, nbase = col0 + wn * 64 + l31;
     switch (p.epi) {
@@ -353,6 +353,178 @@ __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, Piec
     __builtin_amdgcn_s_waitcnt(0);   // stores issued and acknowledged
     STAMP(3);
 #endif
+}
+
+// ---- bf16 matrix kernel, LDS-DMA form (SPLIT = 1) ----------------------------------------------------------------------------------
+// The 128x128 kernel above is bound by operand delivery: the VGPR -> LDS store path (~80 B/clk/CU for ds_write_b128 against 256 B/clk for
+// the fragment reads) and the L2 -> CU path (measured ceiling ~29 B/clk/CU; a 128x128 tile asks 64 B per MFMA clock).  Here
+//   * both operand tiles go global -> LDS directly (global_load_lds_dwordx4: no VGPRs, no ds_write) into a ring of NS slab buffers, NS
+//     slabs requested ahead, counted s_waitcnt vmcnt(N) + raw s_barrier once per slab (a __syncthreads() would drain the queue);
+//   * tiles are 256x256 (8 waves as 2x4, BK = 64: 32 B per MFMA clock, full 128-byte lines per row, 1 workgroup per CU) or 256x128
+//     (4 waves as 2x2, BK = 32, 2 workgroups per CU) for shapes whose 256x256 grid would leave CUs idle; each wave owns a 128x64
+//     output block = 4x2 MFMA tiles, 6 fragment reads per 8 MFMAs;
+//   * the K steps are software pipelined in registers: the fragments of step g + 1 are read while the MFMAs of step g run, and when step
+//     g + 1 opens a new slab the wait + barrier sit between two MFMA groups; once every wave holds the current slab's last fragments
+//     the buffer goes straight back to the DMA.
+// An LDS-DMA instruction writes wave-uniform base + lane * 16 B, so the LDS image is lane-linear [row][BK bf16]; the bank swizzle
+// (16-byte chunk index XOR row / rows-per-256-B) is applied to the per-lane SOURCE address and again on the fragment read.
+template <int BK>
+__device__ __forceinline__ int dma_swz(int row) {
+    constexpr int CPR = BK / 8, RPB = 256 / (BK * 2);      // 16-byte chunks per row, rows per 256-byte bank row
+    return (row / RPB) & (CPR - 1);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm_then_barrier() {      // counted wait for this wave's older LDS-DMA loads, then the workgroup barrier
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");      // "memory": fragment reads stay behind it
+}
+
+template <int WGN, int BK, int NS>
+__global__ __launch_bounds__(WGN * 128, 2) void gemm_bf16_dma_kernel(GemmArgs p, PieceArgs q) {
+    constexpr int BM = 256, BN = 64 * WGN, NW = 2 * WGN, RB = BK * 2, KS = BK / 16;
+    constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = A_BYTES / 1024 / NW, NB = B_BYTES / 1024 / NW;      // 1 KB wave-instructions per wave per slab
+    constexpr int LPS = NA + NB;
+    static_assert(NA >= 1 && NB >= 1 && KS % 2 == 0, "tile / slab shape");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int qq = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+    }
+    const int row0 = (bid / nbn) * BM, col0 = (bid % nbn) * BN;
+    const int nk = q.Kp / BK;
+
+    // per-lane source byte offsets (K slab 0) of this wave's DMA instructions; rows past the matrix edge re-read the last row (those
+    // accumulator rows are never stored)
+    unsigned offa[NA], offb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int o = (wave * NA + i) * 1024 + lane * 16, row = o / RB, ch = (o % RB) / 16;
+        offa[i] = (unsigned)(min(row0 + row, p.M - 1)) * (unsigned)(q.Kp * 2) + (unsigned)((ch ^ dma_swz<BK>(row)) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int o = (wave * NB + i) * 1024 + lane * 16, row = o / RB, ch = (o % RB) / 16;
+        offb[i] = (unsigned)(min(col0 + row, p.N - 1)) * (unsigned)(q.Kp * 2) + (unsigned)((ch ^ dma_swz<BK>(row)) * 16);
+    }
+    const unsigned char* Ag = reinterpret_cast<const unsigned char*>(q.Ap);
+    const unsigned char* Bg = reinterpret_cast<const unsigned char*>(q.Bp);
+
+    auto issue = [&](int kt, int buf) {
+        unsigned char* st = smem_raw + buf * STAGE;
+        const unsigned kb = (unsigned)kt * RB;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ag + offa[i] + kb),
+                                             (__attribute__((address_space(3))) void*)(st + (wave * NA + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bg + offb[i] + kb),
+                                             (__attribute__((address_space(3))) void*)(st + A_BYTES + (wave * NB + i) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets inside a slab image: row * RB + ((2 * ks + half) ^ swz(row)) * 16; the swizzle depends on the row only
+    int ra[4], sa[4], rb[2], sb[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const int row = wm * 128 + t * 32 + l31; ra[t] = row * RB; sa[t] = dma_swz<BK>(row); }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { const int row = wn * 64 + t * 32 + l31; rb[t] = A_BYTES + row * RB; sb[t] = dma_swz<BK>(row); }
+
+    auto rd = [&](const unsigned char* st, int ks, bf16x8 (&a)[4], bf16x8 (&b)[2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) b[t] = *reinterpret_cast<const bf16x8*>(st + rb[t] + (((2 * ks + half) ^ sb[t]) << 4));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const bf16x8*>(st + ra[t] + (((2 * ks + half) ^ sa[t]) << 4));
+    };
+    auto mm_head = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[2]) { acc[0][0] = mfma_bf16(a[0], b[0], acc[0][0]); };
+    auto mm_tail = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[2]) {
+#pragma unroll
+        for (int i = 1; i < 8; ++i) acc[i >> 1][i & 1] = mfma_bf16(a[i >> 1], b[i & 1], acc[i >> 1][i & 1]);
+    };
+    // sched_barrier(0) pins the phase order (left alone, hipcc sinks the fragment reads next to their MFMAs to save registers and waits for
+    // each group with nothing else in flight).  Per K step: first MFMA (its fragments were read during the previous step's MFMAs) | read
+    // the next step's fragments - across a slab boundary: wait + barrier, request slab kt + NS into the buffer just drained - | 7 MFMAs.
+#define D2S_PIN() __builtin_amdgcn_sched_barrier(0)
+    bf16x8 fa[2][4], fb[2][2];
+    // steps 0 .. KS-2 of the slab in `st` (fragments of step 0 in set 0 on entry; on exit set 1 holds step KS-1)
+    auto inner_steps = [&](const unsigned char* st) {
+#pragma unroll
+        for (int ks = 0; ks < KS - 1; ++ks) {
+            mm_head(fa[ks & 1], fb[ks & 1]);
+            D2S_PIN();
+            rd(st, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+            D2S_PIN();
+            mm_tail(fa[ks & 1], fb[ks & 1]);
+            D2S_PIN();
+        }
+    };
+
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+        if (t < nk) issue(t, t);
+    if (nk >= NS) wait_vm_then_barrier<(NS - 1) * LPS>();
+    else wait_vm_then_barrier<0>();
+    rd(smem_raw, 0, fa[0], fb[0]);
+    int buf = 0, kt = 0;
+    for (; kt + NS < nk; ++kt) {          // steady state: slabs kt + 2 .. kt + NS - 1 may still be in flight at the wait
+        inner_steps(smem_raw + buf * STAGE);
+        wait_vm_then_barrier<(NS - 2) * LPS>();
+        mm_head(fa[1], fb[1]);
+        D2S_PIN();
+        issue(kt + NS, buf);
+        buf = (buf + 1 == NS) ? 0 : buf + 1;
+        rd(smem_raw + buf * STAGE, 0, fa[0], fb[0]);
+        D2S_PIN();
+        mm_tail(fa[1], fb[1]);
+        D2S_PIN();
+    }
+    for (; kt + 1 < nk; ++kt) {           // drain: nothing left to request
+        inner_steps(smem_raw + buf * STAGE);
+        wait_vm_then_barrier<0>();
+        mm_head(fa[1], fb[1]);
+        D2S_PIN();
+        buf = (buf + 1 == NS) ? 0 : buf + 1;
+        rd(smem_raw + buf * STAGE, 0, fa[0], fb[0]);
+        D2S_PIN();
+        mm_tail(fa[1], fb[1]);
+        D2S_PIN();
+    }
+    inner_steps(smem_raw + buf * STAGE);
+    mm_head(fa[1], fb[1]);
+    mm_tail(fa[1], fb[1]);
+#undef D2S_PIN
+    __syncthreads();      // every wave is done with the operand images: reuse the LDS for the epilogue's wave-private staging
+    float* stage = reinterpret_cast<float*>(smem_raw) + wave * epi_stage_floats(2);
+    store_tile_dispatch_lds<4, 2, true>(p.epi, p, p.C, acc, row0 + wm * 128, col0 + wn * 64, lane, stage);
+}
+
+template <int WGN, int BK, int NS>
+inline void launch_dma(const GemmArgs& pv, const PieceArgs& q, hipStream_t stream) {
+    constexpr int BN = 64 * WGN;
+    constexpr size_t lds = (size_t)NS * (256 + BN) * BK * 2;
+    static_assert(lds >= 2 * WGN * epi_stage_floats(2) * sizeof(float), "epilogue staging must fit");
+    static_assert(lds <= 160 * 1024, "LDS per CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WGN, BK, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int tiles = ((pv.M + 255) / 256) * ((pv.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_bf16_dma_kernel<WGN, BK, NS>), dim3(tiles), dim3(WGN * 128), lds, stream, pv, q);
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -383,15 +555,52 @@ int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace,
     // D2S_SPLIT_A_INKERNEL = 0 / 1 forces one or the other.
     static const int a_inkernel_env = [] { const char* e = getenv("D2S_SPLIT_A_INKERNEL"); return e ? atoi(e) : -1; }();
     const int col_tiles = (p.N + SBN - 1) / SBN;
-    const bool af32 = p.vecA && (a_inkernel_env >= 0 ? a_inkernel_env != 0 : (split == 1 && col_tiles <= 12));
+    // bf16 (one piece): LDS-DMA kernel for large shapes; D2S_SPLIT_DMA = 0 off, 1 automatic tile choice, 2 / 3 force 256x128 / 256x256
+    static const int dma_env = [] { const char* e = getenv("D2S_SPLIT_DMA"); return e ? atoi(e) : 1; }();
+    // Without a caller-provided bf16 A the kernel needs a conversion pass over A first (6 bytes per element of A against the 2 of reading
+    // it in the matrix kernel): that pays from N ~ 900 on (measured: DeiT-B fc1 / qkv yes, proj / fc2 no).
+    const bool have_a16 = p.a16 != nullptr && split == 1;      // the caller's bf16 copy of A is the piece matrix (Kp == K)
+    const bool dma_shape = dma_env && split == 1 && p.M >= 2048 && p.N >= 128 && epilogue_vec_ok(p) && (have_a16 || p.N >= 1024 || dma_env > 1);
+    bool dma_wide = false;
+    if (dma_shape) {
+        if (Kp % 64 == 0 && p.N >= 256) {
+            // residency rounds of each grid (256 CUs; one 256x256 or two 256x128 workgroups per CU) x relative cost of a tile
+            const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256), t128 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+            static const int cus = [] {
+                int dev = 0, n = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+                return n;
+            }();
+            // cost in units of one 256x256 tile time: a CU runs one 256x256 workgroup or two 256x128 ones (measured 1.17x the time of
+            // one 256x256 for the pair, 0.62x when it has a single one)
+            const long f128 = t128 / (2 * cus), r128 = t128 % (2 * cus);
+            const double c256 = (double)((t256 + cus - 1) / cus);
+            const double c128 = f128 * 1.17 + (r128 == 0 ? 0.0 : r128 <= cus ? 0.62 : 1.17);
+            dma_wide = dma_env == 3 || (dma_env != 2 && c256 <= c128);
+        }
+    }
+    if ((p.c16 || !p.C) && (!epilogue_vec_ok(p) || split != 1)) return D2S_ERR_ARG;      // the bf16 copy is written by the 16-byte epilogue only
+    if (!p.A && !have_a16) return D2S_ERR_ARG;
+    if (have_a16) Ap = static_cast<__bf16*>(const_cast<void*>(p.a16));
+    const bool af32 = !have_a16 && p.vecA && (a_inkernel_env >= 0 ? a_inkernel_env != 0 : (split == 1 && col_tiles <= 12 && !dma_shape));
     if (split == 3) {
         if (!af32) hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)((ea + 255) / 256)), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
         if (b_cols) hipLaunchKernelGGL(split_cols_kernel<3>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB, static_cast<float*>(nullptr));
         else hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)((eb + 255) / 256)), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
     } else {
-        if (!af32) hipLaunchKernelGGL(split_rows_kernel<1>, dim3((unsigned)((ea + 255) / 256)), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
+        if (!af32 && !have_a16) hipLaunchKernelGGL(split_rows_kernel<1>, dim3((unsigned)((ea + 255) / 256)), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
         if (b_cols) hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB, static_cast<float*>(nullptr));
         else hipLaunchKernelGGL(split_rows_kernel<1>, dim3((unsigned)((eb + 255) / 256)), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
+    }
+    if (dma_shape && !af32) {
+        GemmArgs pb = p;
+        pb.vec_epilogue = 1;
+        pb.k_per_slice = Kp;
+        pb.slab_stride = 0;
+        PieceArgs qb{Ap, Bp, Kp};
+        if (dma_wide) launch_dma<4, 64, 2>(pb, qb, stream);
+        else launch_dma<2, 32, 3>(pb, qb, stream);
+        return d2s_check_launch();
     }
     const int tiles = ((p.M + SBM - 1) / SBM) * ((p.N + SBN - 1) / SBN);
     static const int bk = [] { const char* e = getenv("D2S_SPLIT_BK"); return (e && atoi(e) == 16) ? 16 : 32; }();   // 32 measured faster than 16 on every model shape

@@ -19,9 +19,17 @@ __device__ __forceinline__ long map_row(const RowMap& m, long r) {
     return g * m.group_stride + m.offset + t * m.row_stride;
 }
 
+typedef __bf16 ln_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_bf16x4(__bf16* __restrict__ p, const f32x4& o) {      // the bf16 copy a following bf16-mode GEMM reads
+    ln_bf16x4 h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = (__bf16)o[j];
+    *reinterpret_cast<ln_bf16x4*>(p) = h;
+}
+
 template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, RowMap xm, const float* __restrict__ w,
-                                                     const float* __restrict__ b, float* __restrict__ y,
+                                                     const float* __restrict__ b, float* __restrict__ y, __bf16* __restrict__ y16,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      long rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
@@ -66,7 +74,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * wv[j] + bv[j];
-            *reinterpret_cast<f32x4*>(yr + c * 4) = o;
+            if (y) *reinterpret_cast<f32x4*>(yr + c * 4) = o;
+            if (y16) store_bf16x4(y16 + row * D + c * 4, o);
         }
     }
     if (lane == 0) {
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // per wave are 192 float4 = 3 per lane, all lanes busy and 3 loads in flight per lane.  Lane l holds vectors c = l, 64 + l, 128 + l of the
 // concatenated pair; c < 96 belongs to the first row.  The reductions are segmented (one sum per row), same count as before.
 __global__ __launch_bounds__(256) void ln_fwd_pair96_kernel(const float* __restrict__ x, RowMap xm, const float* __restrict__ w,
-                                                            const float* __restrict__ b, float* __restrict__ y,
+                                                            const float* __restrict__ b, float* __restrict__ y, __bf16* __restrict__ y16,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                             long rows, float eps) {
     constexpr int NVEC = 96, D = 384;
@@ -126,7 +135,9 @@ __global__ __launch_bounds__(256) void ln_fwd_pair96_kernel(const float* __restr
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - m) * r * wv[j] + bv[j];
-        *reinterpret_cast<f32x4*>(y + (r0 + (second[i] ? 1 : 0)) * D + col[i] * 4) = o;
+        const long off = (r0 + (second[i] ? 1 : 0)) * D + col[i] * 4;
+        if (y) *reinterpret_cast<f32x4*>(y + off) = o;
+        if (y16) store_bf16x4(y16 + off, o);
     }
     if (lane == 0) {
         if (mean_out) { mean_out[r0] = mean0; if (has1) mean_out[r0 + 1] = mean1; }
@@ -387,28 +398,45 @@ extern "C" {
 // Row addressing for x (and dx in backward): element offset of logical row r is
 //   (r / rows_per_group) * group_stride + offset + (r % rows_per_group) * row_stride.
 // Contiguous [rows, D]: rows_per_group = rows, group_stride = 0, row_stride = D, offset = 0.
-int d2s_layernorm_fwd(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* w,
-                      const float* b, float* y, float* mean, float* rstd, long rows, int D, float eps, hipStream_t stream) {
-    if (!x || !w || !b || !y || rows <= 0 || D <= 0 || D > 4096 || rows_per_group <= 0) return D2S_ERR_ARG;
+static int layernorm_fwd_impl(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* w,
+                              const float* b, float* y, __bf16* y16, float* mean, float* rstd, long rows, int D, float eps, hipStream_t stream) {
+    if (!x || !w || !b || (!y && !y16) || rows <= 0 || D <= 0 || D > 4096 || rows_per_group <= 0) return D2S_ERR_ARG;
     RowMap m{rows_per_group, group_stride, row_stride, offset};
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     if ((D & 3) || ((group_stride | row_stride | offset) & 3)) {
+        if (y16 || !y) return D2S_ERR_ARG;      // the bf16 copy exists for the vector kernels only (D % 4 == 0)
         hipLaunchKernelGGL(ln_fwd_scalar_kernel, grid, block, 0, stream, x, m, w, b, y, mean, rstd, rows, D, eps);
         return d2s_check_launch();
     }
     static const int pair_env = [] { const char* e = getenv("D2S_LN_PAIR"); return e ? atoi(e) : 1; }();
     if (D == 384 && pair_env) {
-        hipLaunchKernelGGL(ln_fwd_pair96_kernel, dim3((unsigned)((rows + 7) / 8)), block, 0, stream, x, m, w, b, y, mean, rstd, rows, eps);
+        hipLaunchKernelGGL(ln_fwd_pair96_kernel, dim3((unsigned)((rows + 7) / 8)), block, 0, stream, x, m, w, b, y, y16, mean, rstd, rows, eps);
         return d2s_check_launch();
     }
     switch (pick_nv(D)) {
-        case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, stream, x, m, w, b, y, mean, rstd, rows, D, eps); break;
-        case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, x, m, w, b, y, mean, rstd, rows, D, eps); break;
-        case 4: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, stream, x, m, w, b, y, mean, rstd, rows, D, eps); break;
-        case 8: hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, stream, x, m, w, b, y, mean, rstd, rows, D, eps); break;
-        default: hipLaunchKernelGGL(ln_fwd_kernel<16>, grid, block, 0, stream, x, m, w, b, y, mean, rstd, rows, D, eps); break;
+        case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, stream, x, m, w, b, y, y16, mean, rstd, rows, D, eps); break;
+        case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, x, m, w, b, y, y16, mean, rstd, rows, D, eps); break;
+        case 4: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, stream, x, m, w, b, y, y16, mean, rstd, rows, D, eps); break;
+        case 8: hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, stream, x, m, w, b, y, y16, mean, rstd, rows, D, eps); break;
+        default: hipLaunchKernelGGL(ln_fwd_kernel<16>, grid, block, 0, stream, x, m, w, b, y, y16, mean, rstd, rows, D, eps); break;
     }
     return d2s_check_launch();
+}
+
+int d2s_layernorm_fwd(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* w,
+                      const float* b, float* y, float* mean, float* rstd, long rows, int D, float eps, hipStream_t stream) {
+    if (!y) return D2S_ERR_ARG;
+    return layernorm_fwd_impl(x, rows_per_group, group_stride, row_stride, offset, w, b, y, nullptr, mean, rstd, rows, D, eps, stream);
+}
+
+// The same LayerNorm with a dense [rows, D] bf16 copy of the output for a following bf16-mode GEMM (its a_bf16); y may be NULL when only
+// the bf16 form is consumed (forward-only passes).  D % 4 == 0.
+int d2s_layernorm_fwd_bf16out(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* w,
+                              const float* b, float* y, void* y_bf16, float* mean, float* rstd, long rows, int D, float eps,
+                              hipStream_t stream) {
+    if (!y_bf16) return D2S_ERR_ARG;
+    return layernorm_fwd_impl(x, rows_per_group, group_stride, row_stride, offset, w, b, y, static_cast<__bf16*>(y_bf16), mean, rstd, rows, D,
+                              eps, stream);
 }
 
 size_t d2s_layernorm_bwd_workspace_bytes(long rows, int D) { return (size_t)bwd_blocks(rows) * 2 * D * sizeof(float); }

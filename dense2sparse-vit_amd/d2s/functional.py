@@ -140,9 +140,35 @@ class BlockFn(torch.autograd.Function):
         x = x.contiguous()
         scale = float(_DH) ** -0.5 if scale is None else float(scale)     # Attention.scale = qk_scale or head_dim ** -0.5 (:188)
         cmap = ops.contiguous_map(M, D)
+        hidden = fc1w.shape[0]
+        # bf16 arithmetic mode: LayerNorm, the attention forward and the fc1 epilogue also emit the bf16 form of what the next GEMM
+        # multiplies, and that GEMM reads it instead of converting its fp32 operand (no conversion passes on the forward path)
+        io = ops.bf16_io() and D % 32 == 0 and hidden % 32 == 0 and x.is_cuda
+        io_attn = io and policy is None and ops._BF16_ATTENTION
         if not any(ctx.needs_input_grad):
             # forward-only (the frozen teacher under no_grad, eval): no LayerNorm statistics, no GELU pre-activation copy (155 MB per
-            # block at B=128), nothing saved
+            # block at B=128), nothing saved; on the bf16 data path not even the fp32 form of the GEMM inputs
+            if io:
+                _, _, _, ln1h = ops.layernorm_fwd_bf16(x, cmap, n1w, n1b, M, D, eps, stats=False, want_f32=False)
+                qkv = ops.linear_fwd(None, qkvw, qkvb, a16=ln1h)
+                del ln1h
+                if io_attn:
+                    ao, _, cls_row, aoh = ops.attn_fwd_bf16io(qkv, B, n, heads, scale, want_cls, want_f32=False)
+                elif policy is None:
+                    (ao, _, cls_row), aoh = ops.attn_fwd(qkv, B, n, heads, scale, want_cls), None
+                else:
+                    (ao, _, _, cls_row), aoh = ops.attn_policy_fwd(qkv, policy, B, n, heads, scale, want_cls=want_cls), None
+                del qkv
+                x1 = ops.linear_fwd(ao, projw, projb, epi=ops.EPI_BIAS_RESID, aux=x.view(M, D), a16=aoh)
+                del ao, aoh
+                _, _, _, ln2h = ops.layernorm_fwd_bf16(x1, cmap, n2w, n2b, M, D, eps, stats=False, want_f32=False)
+                hh = ops.bf16_buffer(M, hidden, x.device)
+                ops.linear_fwd(None, fc1w, fc1b, epi=ops.EPI_BIAS_GELU, a16=ln2h, c16=hh, want_f32=False)
+                del ln2h
+                y = ops.linear_fwd(None, fc2w, fc2b, epi=ops.EPI_BIAS_RESID, aux=x1, a16=hh)
+                if cls_row is None:
+                    cls_row = torch.empty((0,), device=x.device)
+                return y.view(B, n, D), cls_row
             ln1, _, _ = ops.layernorm_fwd(x, cmap, n1w, n1b, M, D, eps, stats=False)
             qkv = ops.linear_fwd(ln1, qkvw, qkvb)
             del ln1
@@ -158,19 +184,33 @@ class BlockFn(torch.autograd.Function):
             if cls_row is None:
                 cls_row = torch.empty((0,), device=x.device)
             return y.view(B, n, D), cls_row
-        ln1, mean1, rstd1 = ops.layernorm_fwd(x, cmap, n1w, n1b, M, D, eps)
-        qkv = ops.linear_fwd(ln1, qkvw, qkvb)
+        ln1h = aoh = ln2h = hh = None
+        if io:
+            ln1, mean1, rstd1, ln1h = ops.layernorm_fwd_bf16(x, cmap, n1w, n1b, M, D, eps)
+        else:
+            ln1, mean1, rstd1 = ops.layernorm_fwd(x, cmap, n1w, n1b, M, D, eps)
+        qkv = ops.linear_fwd(ln1, qkvw, qkvb, a16=ln1h)
+        del ln1h
         cinv = None
-        if policy is None:
+        if io_attn:
+            ao, lse, cls_row, aoh = ops.attn_fwd_bf16io(qkv, B, n, heads, scale, want_cls)
+        elif policy is None:
             ao, lse, cls_row = ops.attn_fwd(qkv, B, n, heads, scale, want_cls)
         else:   # dynamic keep ratio: softmax_with_policy fused into the attention pass (:195-214)
             ao, lse, cinv, cls_row = ops.attn_policy_fwd(qkv, policy, B, n, heads, scale, want_cls=want_cls)
         x2d = x.view(M, D)
-        x1 = ops.linear_fwd(ao, projw, projb, epi=ops.EPI_BIAS_RESID, aux=x2d)
-        ln2, mean2, rstd2 = ops.layernorm_fwd(x1, cmap, n2w, n2b, M, D, eps)
-        z = torch.empty((M, fc1w.shape[0]), dtype=torch.float32, device=x.device)
-        h = ops.linear_fwd(ln2, fc1w, fc1b, epi=ops.EPI_BIAS_GELU, aux_out=z)
-        y = ops.linear_fwd(h, fc2w, fc2b, epi=ops.EPI_BIAS_RESID, aux=x1)
+        x1 = ops.linear_fwd(ao, projw, projb, epi=ops.EPI_BIAS_RESID, aux=x2d, a16=aoh)
+        del aoh
+        if io:
+            ln2, mean2, rstd2, ln2h = ops.layernorm_fwd_bf16(x1, cmap, n2w, n2b, M, D, eps)
+            hh = ops.bf16_buffer(M, hidden, x.device)
+        else:
+            ln2, mean2, rstd2 = ops.layernorm_fwd(x1, cmap, n2w, n2b, M, D, eps)
+        z = torch.empty((M, hidden), dtype=torch.float32, device=x.device)
+        h = ops.linear_fwd(ln2, fc1w, fc1b, epi=ops.EPI_BIAS_GELU, aux_out=z, a16=ln2h, c16=hh)
+        del ln2h
+        y = ops.linear_fwd(h, fc2w, fc2b, epi=ops.EPI_BIAS_RESID, aux=x1, a16=hh)
+        del hh
         ctx.save_for_backward(x, n1w, qkvw, projw, n2w, fc1w, fc2w, mean1, rstd1, ln1, qkv, ao, lse, x1, mean2, rstd2, ln2, z, h,
                               n1b, qkvb, projb, n2b, fc1b, fc2b)
         ctx.policy = (policy, cinv)
@@ -197,9 +237,11 @@ class BlockFn(torch.autograd.Function):
 
         # ---- MLP branch ----
         grads[11], grads[12] = ops.linear_param_grads(gy, h, fc2w, fc2b, wants[11], wants[12])
-        dz = ops.linear_dgrad(gy, fc2w, epi=ops.EPI_MUL_GELU_GRAD, aux=z)
+        dzh = ops.bf16_buffer(M, z.shape[1], dev) if (ops.bf16_io() and z.shape[1] % 32 == 0 and D % 32 == 0 and gy.is_cuda) else None
+        dz = ops.linear_dgrad(gy, fc2w, epi=ops.EPI_MUL_GELU_GRAD, aux=z, c16=dzh)
         grads[9], grads[10] = ops.linear_param_grads(dz, ln2, fc1w, fc1b, wants[9], wants[10])
-        dln2 = ops.linear_dgrad(dz, fc1w)
+        dln2 = ops.linear_dgrad(dz, fc1w, a16=dzh)
+        del dzh
         g1 = torch.empty((M, D), dtype=torch.float32, device=dev)
         dn2w = new(n2w) if (wants[7] or wants[8]) else None
         dn2b = new(n2b) if dn2w is not None else None

@@ -18,6 +18,7 @@ P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ct
 _SIGS = {
     "d2s_gemm_f32_workspace_bytes": (Z, [I, I, I, I, I]),
     "d2s_gemm_f32": (I, [I, P, L, P, L, P, L, I, I, I, I, P, P, L, P, I, I, I, I, I, P, Z]),
+    "d2s_gemm_f32_bf16io": (I, [I, P, L, P, L, P, L, I, I, I, I, P, P, L, P, P, P, P, Z]),
     "d2s_linear_wgrad_workspace_bytes": (Z, [I, I, I, I]),
     "d2s_linear_wgrad_f32": (I, [P, L, P, L, P, L, P, I, I, I, I, I, P, Z]),
     "d2s_batchnorm_workspace_bytes": (Z, [L, I]),
@@ -28,6 +29,7 @@ _SIGS = {
     "d2s_colsum_workspace_bytes": (Z, [I, I]),
     "d2s_colsum_f32": (I, [P, L, I, I, P, I, P, Z]),
     "d2s_layernorm_fwd": (I, [P, L, L, L, L, P, P, P, P, P, L, I, F]),
+    "d2s_layernorm_fwd_bf16out": (I, [P, L, L, L, L, P, P, P, P, P, P, L, I, F]),
     "d2s_layernorm_bwd_workspace_bytes": (Z, [L, I]),
     "d2s_layernorm_bwd": (I, [P, L, L, L, L, P, P, P, P, P, P, P, P, I, I, L, I, P, Z]),
     "d2s_softmax_rows": (I, [P, P, I, I]),
@@ -49,6 +51,7 @@ _SIGS = {
     "d2s_performer_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, F, P, Z]),
     "d2s_attn_fwd_f32": (I, [P, P, P, P, I, I, I, F]),
     "d2s_attn_fwd_bf16": (I, [P, P, P, P, I, I, I, F]),
+    "d2s_attn_fwd_bf16_bf16out": (I, [P, P, P, P, P, I, I, I, F]),
     "d2s_attn_bwd_f32": (I, [P, P, P, P, P, P, I, I, I, F]),
     "d2s_attn_bwd_bf16": (I, [P, P, P, P, P, P, I, I, I, F]),
     "d2s_attn_delta": (I, [P, P, P, I, I, I]),

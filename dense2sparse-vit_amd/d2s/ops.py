@@ -34,30 +34,55 @@ def _f32(t):
     return t
 
 
+# bf16 data path of the bf16 arithmetic mode: producers (LayerNorm, the attention forward, GEMM epilogues) emit a bf16 copy of what the
+# next GEMM multiplies, and that GEMM reads it directly instead of converting its fp32 operand first (d2s_gemm_f32_bf16io).
+_BF16_IO = os.environ.get("D2S_BF16_IO", "1") != "0"
+
+
+def bf16_io():
+    return _BF16_IO and get_gemm_mode() == GEMM_BF16
+
+
+def bf16_buffer(rows, cols, device):
+    return torch.empty((rows, cols), dtype=torch.bfloat16, device=device)
+
+
 def gemm(layout, A, lda, B, ldb, C, ldc, M, N, K, epi=EPI_NONE, bias=None, aux=None, ldaux=0, aux_out=None, aux_rows=0,
-         remap_rows=0, remap_skip=0, accumulate=False):
+         remap_rows=0, remap_skip=0, accumulate=False, a16=None, c16=None):
     mode = get_gemm_mode()
     qk = (layout, M, N, K, mode)
     need = _WS_NEED.get(qk)
     if need is None:
         need = _WS_NEED[qk] = lib.query("d2s_gemm_f32_workspace_bytes", layout, M, N, K, mode)
-    ws = workspace(need, C.device) if need else None
+    dev = C.device if C is not None else c16.device
+    ws = workspace(need, dev) if need else None
+    if a16 is not None or c16 is not None:
+        assert mode == GEMM_BF16 and not accumulate and remap_rows == 0 and aux_rows == 0
+        assert a16 is None or (a16.dtype == torch.bfloat16 and a16.is_contiguous() and tuple(a16.shape) == (M, K)), "a16 must be dense bf16 [M, K]"
+        assert c16 is None or (c16.dtype == torch.bfloat16 and c16.is_contiguous() and tuple(c16.shape) == (M, N)), "c16 must be dense bf16 [M, N]"
+        lib.call("d2s_gemm_f32_bf16io", layout, lib.ptr(A), lda, lib.ptr(B), ldb, lib.ptr(C), ldc, M, N, K, epi, lib.ptr(bias),
+                 lib.ptr(aux), ldaux, lib.ptr(aux_out), lib.ptr(a16), lib.ptr(c16), lib.ptr(ws), ws.numel() if ws is not None else 0)
+        return C
     lib.call("d2s_gemm_f32", layout, lib.ptr(A), lda, lib.ptr(B), ldb, lib.ptr(C), ldc, M, N, K, epi, lib.ptr(bias),
              lib.ptr(aux), ldaux, lib.ptr(aux_out), aux_rows, remap_rows, remap_skip, int(accumulate), mode, lib.ptr(ws),
              ws.numel() if ws is not None else 0)
     return C
 
 
-def linear_fwd(x, W, bias=None, epi=None, aux=None, aux_out=None, out=None):
-    """y[M,N] = epi(x[M,K] @ W[N,K]^T + bias).  nn.Linear forward (F.linear)."""
-    _f32(x), _f32(W)
-    M, K = x.shape
+def linear_fwd(x, W, bias=None, epi=None, aux=None, aux_out=None, out=None, a16=None, c16=None, want_f32=True):
+    """y[M,N] = epi(x[M,K] @ W[N,K]^T + bias).  nn.Linear forward (F.linear).
+    bf16 mode only: a16 = bf16 copy of x (x itself may then be None), c16 = bf16 [M, N] buffer that receives a copy of y;
+    want_f32=False (needs c16) skips the fp32 result and returns None."""
+    _f32(W)
+    if x is not None:
+        _f32(x)
+    M, K = (x if x is not None else a16).shape
     N = W.shape[0]
-    if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if out is None and want_f32:
+        out = torch.empty((M, N), dtype=torch.float32, device=W.device)
     if epi is None:
         epi = EPI_BIAS if bias is not None else EPI_NONE
-    return gemm(NT, x, K, W, K, out, N, M, N, K, epi, bias, aux, N if aux is not None else 0, aux_out)
+    return gemm(NT, x, K, W, K, out, N, M, N, K, epi, bias, aux, N if aux is not None else 0, aux_out, a16=a16, c16=c16)
 
 
 # ---- k-contiguous copies W^T of Linear weights for the input-gradient GEMM ----
@@ -143,13 +168,15 @@ class TransposedArena:
             _WT[w.data_ptr()] = (weights_epoch, w._version, tuple(w.shape), wt)
 
 
-def linear_dgrad(dy, W, epi=EPI_NONE, aux=None, out=None):
-    """dx[M,K] = epi(dy[M,N] @ W[N,K])."""
+def linear_dgrad(dy, W, epi=EPI_NONE, aux=None, out=None, a16=None, c16=None):
+    """dx[M,K] = epi(dy[M,N] @ W[N,K]).  bf16 mode only: a16 = bf16 copy of dy, c16 = bf16 [M, K] buffer receiving a copy of dx."""
     _f32(dy), _f32(W)
     M, N = dy.shape
     K = W.shape[1]
     if out is None:
         out = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    if a16 is not None or c16 is not None:
+        return gemm(NN, dy, N, W, K, out, K, M, K, N, epi, None, aux, K if aux is not None else 0, a16=a16, c16=c16)
     if get_gemm_mode() == GEMM_EXACT and M >= _DGRAD_NT_MIN_ROWS and (N % 16 == 0) and (K % 4 == 0) and _in_weight_arena(W.data_ptr()):
         return gemm(NT, dy, N, transposed_weight(W), N, out, K, M, K, N, epi, None, aux, K if aux is not None else 0)
     return gemm(NN, dy, N, W, K, out, K, M, K, N, epi, None, aux, K if aux is not None else 0)
@@ -260,6 +287,17 @@ def layernorm_fwd(x, rowmap, w, b, rows, D, eps, stats=True):
     lib.call("d2s_layernorm_fwd", lib.ptr(x), *rowmap, lib.ptr(w), lib.ptr(b), lib.ptr(y), lib.ptr(mean), lib.ptr(rstd),
              rows, D, float(eps))
     return y, mean, rstd
+
+
+def layernorm_fwd_bf16(x, rowmap, w, b, rows, D, eps, stats=True, want_f32=True):
+    """LayerNorm forward that also (or only: want_f32=False) writes the bf16 copy a bf16-mode GEMM reads.  -> (y or None, mean, rstd, y16)"""
+    y = torch.empty((rows, D), dtype=torch.float32, device=x.device) if want_f32 else None
+    y16 = bf16_buffer(rows, D, x.device)
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device) if stats else None
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device) if stats else None
+    lib.call("d2s_layernorm_fwd_bf16out", lib.ptr(x), *rowmap, lib.ptr(w), lib.ptr(b), lib.ptr(y), lib.ptr(y16), lib.ptr(mean),
+             lib.ptr(rstd), rows, D, float(eps))
+    return y, mean, rstd, y16
 
 
 def layernorm_bwd(x, rowmap, dy, w, mean, rstd, dx, add_src, dw, db, rows, D, accumulate_wb=False, relu_mask=False):
@@ -408,6 +446,16 @@ def attn_fwd(qkv, B, n, H, scale, want_cls=True):
     entry = "d2s_attn_fwd_bf16" if (get_gemm_mode() == GEMM_BF16 and _BF16_ATTENTION) else "d2s_attn_fwd_f32"
     lib.call(entry, lib.ptr(qkv), lib.ptr(out), lib.ptr(lse), lib.ptr(cls_row), B, n, H, float(scale))
     return out, lse, cls_row
+
+
+def attn_fwd_bf16io(qkv, B, n, H, scale, want_cls=True, want_f32=True):
+    """bf16-mode attention forward that also (or only) writes the bf16 copy of its output.  -> (out or None, lse, cls_row, out16)"""
+    out = torch.empty((B * n, H * 64), dtype=torch.float32, device=qkv.device) if want_f32 else None
+    out16 = bf16_buffer(B * n, H * 64, qkv.device)
+    lse = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device)
+    cls_row = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device) if want_cls else None
+    lib.call("d2s_attn_fwd_bf16_bf16out", lib.ptr(qkv), lib.ptr(out), lib.ptr(out16), lib.ptr(lse), lib.ptr(cls_row), B, n, H, float(scale))
+    return out, lse, cls_row, out16
 
 
 def attn_bwd(qkv, out, dout, lse, B, n, H, scale):

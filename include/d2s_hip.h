@@ -50,6 +50,14 @@ int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb,
                  int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, int aux_rows,
                  int remap_rows_per_img, int remap_skip, int accumulate, int mode, void* workspace, size_t workspace_bytes,
                  d2s_stream_t stream);
+/* bf16 data path of mode 2 (BASELINE config 5's bf16 regime; what torch.autocast does around F.linear, vit_models/dynamic_vit.py:169-175,
+ * 218-231): the same GEMM with bf16 side channels.  a_bf16 (optional): the A operand already rounded to bf16, dense [M][K], K % 32 == 0 -
+ * the call skips its conversion pass over A (A, if given, must hold the same values; it may be NULL).  c_bf16 (optional): a dense [M][N]
+ * bf16 copy of the result, N % 32 == 0, written by the same epilogue - the a_bf16 of the next GEMM (C may then be NULL).  Producers of
+ * a_bf16 other than a GEMM: d2s_layernorm_fwd_bf16out, d2s_attn_fwd_bf16_bf16out.  NT / NN layouts; workspace as d2s_gemm_f32 in mode 2. */
+int d2s_gemm_f32_bf16io(int layout, const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
+                        int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, const void* a_bf16, void* c_bf16,
+                        void* workspace, size_t workspace_bytes, d2s_stream_t stream);
 /* nn.Linear parameter gradients in one pass over dy (autograd of F.linear at vit_models/dynamic_vit.py:169-175,218,231,491-531):
  * dW[n_out,n_in] (+)= dy[tokens,n_out]^T x[tokens,n_in];  db[n_out] (+)= column sums of dy (db may be NULL).  Exact fp32 MFMA,
  * deterministic split-K over the token rows; the bias gradient is folded out of the dy tiles the GEMM streams anyway. */
@@ -70,6 +78,10 @@ int d2s_colsum_f32(const float* X, long ldx, int M, int N, float* out, int accum
 /* ---- LayerNorm (vit_models/dynamic_vit.py:245,250,678,993 and the predictor's LayerNorms :491-531) -------------- */
 int d2s_layernorm_fwd(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* w,
                       const float* b, float* y, float* mean, float* rstd, long rows, int D, float eps, d2s_stream_t stream);
+/* the same with a dense [rows, D] bf16 copy of the output for a following bf16-mode GEMM (y may be NULL when only that form is consumed) */
+int d2s_layernorm_fwd_bf16out(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* w,
+                              const float* b, float* y, void* y_bf16, float* mean, float* rstd, long rows, int D, float eps,
+                              d2s_stream_t stream);
 size_t d2s_layernorm_bwd_workspace_bytes(long rows, int D);
 /* dx[map(r)] = (add_src ? add_src[map(r)] : 0) + mask * dLN/dx; relu_mask folds a preceding ReLU's backward in. */
 int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* dy,
@@ -85,6 +97,9 @@ int d2s_attn_fwd_f32(const float* qkv, float* out, float* lse, float* cls_row, i
  * arithmetic mode.  The fp32 backward below works from its outputs unchanged. */
 int d2s_attn_fwd_bf16(const float* qkv, float* out, float* lse, float* cls_row, int B, int n, int H, float scale,
                       d2s_stream_t stream);
+/* ... with a dense [B, n, H*64] bf16 copy of the output for the projection GEMM (out may be NULL in forward-only passes) */
+int d2s_attn_fwd_bf16_bf16out(const float* qkv, float* out, void* out_bf16, float* lse, float* cls_row, int B, int n, int H, float scale,
+                              d2s_stream_t stream);
 int d2s_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws,
                      int B, int n, int H, float scale, d2s_stream_t stream);
 /* the two independent halves of d2s_attn_bwd_f32 (delta_ws [B,H,n] from d2s_attn_delta): dQ, and dK / dV; they write disjoint parts of

@@ -317,6 +317,124 @@ def test_gemm_split_modes(ops, mode, rtol, atol):
         ops.set_gemm_mode(0)
 
 
+@pytest.mark.parametrize("mode,rtol,atol", [(1, 1e-4, 2e-5), (2, 3e-2, 3e-2)])
+@pytest.mark.parametrize("M,N,K", [(4096, 1536, 384), (2500, 384, 1536), (2048, 768, 96), (3000, 1152, 384), (2304, 300, 64)])
+def test_gemm_split_modes_big_tiles(ops, mode, rtol, atol, M, N, K):
+    """Shapes that take the large-tile LDS-DMA kernel in bf16 mode (M >= 2048; 256x256 or 256x128 tiles by shape, the GPU round also
+    runs this file with D2S_SPLIT_DMA=2 / 3 to force either): forward with every epilogue the model uses on that path (bias, GELU +
+    pre-activation copy, residual, GELU-gradient mask) and the input-gradient layout, ragged edges in M and N included, in both
+    arithmetic modes at the tolerances of the 128x128 kernel."""
+    ops.set_gemm_mode(mode)
+    try:
+        x, w, b = _rand("bx", (M, K), seed=M), _rand("bw", (N, K), 0.05, seed=N), _rand("bb", (N,), 0.1)
+        r = _rand("br", (M, N), seed=K)
+        ref = F.linear(x, w, b)
+        xd, wd, bd, rd = x.to(_dev()), w.to(_dev()), b.to(_dev()), r.to(_dev())
+        np.testing.assert_allclose(ops.linear_fwd(xd, wd, bd).cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol)
+        z = torch.empty((M, N), device=_dev())
+        h = ops.linear_fwd(xd, wd, bd, epi=ops.EPI_BIAS_GELU, aux_out=z)
+        np.testing.assert_allclose(z.cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol)
+        np.testing.assert_allclose(h.cpu().numpy(), F.gelu(ref).numpy(), rtol=rtol, atol=atol)
+        np.testing.assert_allclose(ops.linear_fwd(xd, wd, bd, epi=ops.EPI_BIAS_RESID, aux=rd).cpu().numpy(), (ref + r).numpy(), rtol=rtol, atol=atol)
+        dy = _rand("bdy", (M, N), seed=M + N)
+        dref = dy @ w
+        np.testing.assert_allclose(ops.linear_dgrad(dy.to(_dev()), wd).cpu().numpy(), dref.numpy(), rtol=rtol, atol=atol * 10)
+        if K % 4 == 0:
+            zz = _rand("bz", (M, K), seed=7)
+            zt = zz.clone().requires_grad_(True)
+            F.gelu(zt).backward(dref)
+            got = ops.linear_dgrad(dy.to(_dev()), wd, epi=ops.EPI_MUL_GELU_GRAD, aux=zz.to(_dev())).cpu()
+            np.testing.assert_allclose(got.numpy(), zt.grad.numpy(), rtol=rtol, atol=atol * 10)
+    finally:
+        ops.set_gemm_mode(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1536, 384), (2500, 384, 1536), (394, 1152, 384), (3000, 768, 768), (2304, 3072, 768)])
+def test_gemm_bf16_io(ops, M, N, K):
+    """d2s_gemm_f32_bf16io: with a16 = bf16(x) the result is the product of the bf16-rounded operands accumulated in fp32 (products of
+    bf16 numbers are exact in fp32, so only the summation order separates it from a float64 product of the same rounded operands:
+    rtol 2e-5); c16 is bit-for-bit bf16(C); A / C may be omitted when their bf16 forms are given; NT and NN layouts, GELU epilogue with
+    its pre-activation copy."""
+    ops.set_gemm_mode(2)
+    try:
+        x, w, b = _rand("ix", (M, K), seed=M), _rand("iw", (N, K), 0.05, seed=N), _rand("ib", (N,), 0.1)
+        xr, wr = x.bfloat16().float(), w.bfloat16().float()
+        ref = (xr.double() @ wr.double().t() + b.double()).float()
+        xd, wd, bd = x.to(_dev()), w.to(_dev()), b.to(_dev())
+        x16 = xd.bfloat16()
+        c16 = torch.empty((M, N), dtype=torch.bfloat16, device=_dev())
+        got = ops.linear_fwd(xd, wd, bd, a16=x16, c16=c16)
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+        assert torch.equal(c16, got.bfloat16())
+        # no fp32 A, no fp32 C
+        c16b = torch.empty_like(c16)
+        assert ops.linear_fwd(None, wd, bd, a16=x16, c16=c16b, want_f32=False) is None
+        assert torch.equal(c16b, c16)
+        # GELU epilogue: pre-activation copy fp32, bf16 copy of the activation
+        z = torch.empty((M, N), device=_dev())
+        h = ops.linear_fwd(xd, wd, bd, epi=ops.EPI_BIAS_GELU, aux_out=z, a16=x16, c16=c16)
+        np.testing.assert_allclose(z.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(h.cpu().numpy(), F.gelu(ref).numpy(), rtol=1e-4, atol=2e-5)
+        assert torch.equal(c16, h.bfloat16())
+        # input-gradient layout: dx = dy @ W with a16 = bf16(dy) and a bf16 copy of dx
+        dy = _rand("idy", (M, N), seed=M + N)
+        dref = (dy.bfloat16().double() @ wr.double()).float()
+        dyd = dy.to(_dev())
+        d16 = torch.empty((M, K), dtype=torch.bfloat16, device=_dev())
+        dx = ops.linear_dgrad(dyd, wd, a16=dyd.bfloat16(), c16=d16)
+        np.testing.assert_allclose(dx.cpu().numpy(), dref.numpy(), rtol=2e-5, atol=2e-4)
+        assert torch.equal(d16, dx.bfloat16())
+    finally:
+        ops.set_gemm_mode(0)
+
+
+def test_bf16_io_rejected_outside_bf16_mode(ops):
+    """The bf16 side channels exist in mode 2 only: every other use is an argument error, not a silent fp32 path."""
+    from d2s import lib
+    x, w = _rand("rx", (256, 64)).to(_dev()), _rand("rw", (128, 64)).to(_dev())
+    out = torch.empty((256, 128), device=_dev())
+    ws = torch.empty(1 << 24, dtype=torch.uint8, device=_dev())
+    # K % 32 != 0 for a16
+    x2, w2 = _rand("rx2", (256, 40)).to(_dev()), _rand("rw2", (128, 40)).to(_dev())
+    with pytest.raises(RuntimeError):
+        lib.call("d2s_gemm_f32_bf16io", 0, lib.ptr(x2), 40, lib.ptr(w2), 40, lib.ptr(out), 128, 256, 128, 40, 0, None, None, 0, None,
+                 lib.ptr(x2.bfloat16()), None, lib.ptr(ws), ws.numel())
+    # the weight-gradient layout has no bf16 side channel
+    with pytest.raises(RuntimeError):
+        lib.call("d2s_gemm_f32_bf16io", 2, lib.ptr(x), 64, lib.ptr(w), 64, lib.ptr(out), 128, 256, 128, 64, 0, None, None, 0, None,
+                 lib.ptr(x.bfloat16()), None, lib.ptr(ws), ws.numel())
+
+
+@pytest.mark.parametrize("rows,D", [(197 * 3, 384), (1000, 768), (77, 192), (130, 1536)])
+def test_layernorm_fwd_bf16out(ops, rows, D):
+    """d2s_layernorm_fwd_bf16out: fp32 output identical to d2s_layernorm_fwd, the bf16 copy is its rounding, and the bf16-only form
+    (no fp32 output, no statistics) writes the same bf16 values."""
+    x, w, b = _rand("lx", (rows, D)).to(_dev()), _rand("lw", (D,), 0.5).to(_dev()) + 1, _rand("lb", (D,), 0.1).to(_dev())
+    cmap = ops.contiguous_map(rows, D)
+    y, mean, rstd = ops.layernorm_fwd(x, cmap, w, b, rows, D, 1e-6)
+    y2, mean2, rstd2, y16 = ops.layernorm_fwd_bf16(x, cmap, w, b, rows, D, 1e-6)
+    assert torch.equal(y, y2) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    assert torch.equal(y16, y.bfloat16())
+    y3, m3, r3, y16b = ops.layernorm_fwd_bf16(x, cmap, w, b, rows, D, 1e-6, stats=False, want_f32=False)
+    assert y3 is None and m3 is None and r3 is None and torch.equal(y16b, y16)
+
+
+def test_attn_fwd_bf16out(ops):
+    """d2s_attn_fwd_bf16_bf16out: same fp32 outputs as d2s_attn_fwd_bf16, bf16 copy = rounding of the output, and the bf16-only form."""
+    B, n, H = 3, 197, 6
+    qkv = _rand("aq", (B * n, 3 * H * 64), 0.5).to(_dev())
+    ops.set_gemm_mode(2)
+    try:
+        out, lse, cls_row = ops.attn_fwd(qkv, B, n, H, 0.125, True)
+        out2, lse2, cls2, o16 = ops.attn_fwd_bf16io(qkv, B, n, H, 0.125, True)
+        assert torch.equal(out, out2) and torch.equal(lse, lse2) and torch.equal(cls_row, cls2)
+        assert torch.equal(o16, out.bfloat16())
+        out3, _, _, o16b = ops.attn_fwd_bf16io(qkv, B, n, H, 0.125, False, want_f32=False)
+        assert out3 is None and torch.equal(o16b, o16)
+    finally:
+        ops.set_gemm_mode(0)
+
+
 @pytest.mark.parametrize("tokens,n_out,n_in", [(197 * 8, 384, 1536), (1000, 96, 192), (130, 10, 24), (4100, 200, 72)])
 def test_linear_wgrad_bf16_mode(ops, tokens, n_out, n_in):
     """Mode 2 runs the weight gradient on the bf16 matrix cores (transposing split + K-sliced pieces kernel + ordered combine);

@@ -439,6 +439,61 @@ def test_full_size_train_step_deterministic_and_batch_independent():
     np.testing.assert_allclose(half["cls_attn"].cpu().numpy(), cls_attn[:64].cpu().numpy(), rtol=1e-5, atol=1e-7)
 
 
+def test_bf16_data_path_full_size_matches_per_call_conversion():
+    """bf16 mode at a size where the LDS-DMA kernel and the bf16 side channels are what runs (DeiT-S 224, keep 0.5, batch 32: M = 6304
+    token rows).  (1) Determinism: two identical steps give bit-identical losses and gradients.  (2) The bf16 data path (LayerNorm /
+    attention / GELU epilogue emitting the next GEMM's bf16 operand) multiplies exactly the numbers the per-call conversion path
+    (D2S_BF16_IO=0) multiplies - the same roundings of the same fp32 values - so with the selection replayed the two differ only by the
+    fp32 summation order of the kernels that ran: logits rtol 1e-3, every gradient within 2 % relative L2 of the other path's."""
+    import vit_models
+    from d2s import synth, ops
+    from d2s.engine import TrainStep
+    dev = torch.device("cuda:0")
+    B = 32
+    x = _t(synth.images(B, 3, 224, seed=3)).to(dev)
+    y = _t(synth.labels(B, 1000, seed=3)).to(dev)
+    args = types.SimpleNamespace(keep_ratios=[0.5], mask_loss_type="kl_div", mixup=0.0, patch_score_threshold=None, step=0)
+
+    def step(io, override, reps):
+        saved = ops._BF16_IO
+        ops._BF16_IO = io
+        ops.set_gemm_mode(ops.GEMM_BF16)
+        try:
+            torch.manual_seed(0)
+            student = vit_models.dynamic_vit_small_patch16_224_student([3], [0.5], topk_selection=True, predictor_loss_type="kl_div").to(dev)
+            teacher = vit_models.dynamic_vit_small_patch16_224_teacher().to(dev)
+            student.kept_token_override = override
+            ts = TrainStep(student, teacher, args, warmup_steps=0)
+            student.train()
+            outs = []
+            for _ in range(reps):
+                loss, info = ts.forward_losses(x, y)
+                ts.opt.zero_grad()
+                loss.backward()
+                torch.cuda.synchronize()
+                outs.append((loss.detach().clone(), info["kept"][0].clone(), info["logits_s"].detach().clone(), info["logits_t"].clone(),
+                             ts.arena.grads.clone()))
+            names = [(n, p.numel()) for n, p in student.named_parameters()]
+        finally:
+            ops.set_gemm_mode(ops.GEMM_EXACT)
+            ops._BF16_IO = saved
+        return outs, names, ts
+
+    on, names, ts_on = step(True, None, 2)
+    assert torch.equal(on[0][0], on[1][0]) and torch.equal(on[0][2], on[1][2]) and torch.equal(on[0][4], on[1][4]), "bf16 data path is not deterministic"
+    assert torch.isfinite(on[0][4]).all() and float(on[0][4].abs().max()) > 0
+    kept = on[0][1].cpu()
+    on_r, _, ts_a = step(True, [kept], 1)
+    off_r, _, ts_b = step(False, [kept], 1)
+    np.testing.assert_allclose(on_r[0][3].cpu().numpy(), off_r[0][3].cpu().numpy(), rtol=1e-3, atol=1e-4)      # teacher logits
+    np.testing.assert_allclose(on_r[0][2].cpu().numpy(), off_r[0][2].cpu().numpy(), rtol=1e-3, atol=1e-4)      # student logits
+    np.testing.assert_allclose(float(on_r[0][0]), float(off_r[0][0]), rtol=1e-4)
+    ga, gb = on_r[0][4].double(), off_r[0][4].double()
+    rel = float((ga - gb).norm() / gb.norm())
+    assert rel < 2e-2, f"gradients of the two bf16 paths differ by {rel:.3e} relative L2"
+    print(f"[bf16 data path vs per-call conversion] loss {float(on_r[0][0]):.6f} / {float(off_r[0][0]):.6f}, gradient relative L2 {rel:.3e}")
+
+
 @pytest.mark.parametrize("name", HIP_CASES)
 def test_split_gemm_mode_keeps_fp32_parity(name):
     """GEMM mode 1 (bf16x3 split on the bf16 matrix cores) on EVERY model case of the parity suite: same assertions as the exact mode -

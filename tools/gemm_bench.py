@@ -11,21 +11,22 @@ from d2s import lib
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0      # 0 exact f32 MFMA, 1 bf16x3 split (fp32-class), 2 bf16
 ops.set_gemm_mode(mode)
 print("gemm mode", mode)
-B = int(os.environ.get("D2S_BENCH_B", "128"))
+base = os.environ.get("D2S_BENCH_MODEL", "small") == "base"      # DeiT-B 384x384 keep 0.3 (config 5) instead of DeiT-S 224 keep 0.5
+B = int(os.environ.get("D2S_BENCH_B", "64" if base else "128"))
+D = 768 if base else 384
 shapes = []
-for n, tag in ((197, "teacher/student n=197"), (99, "student n=99")):
+for n, tag in (((577, "teacher/student n=577"), (173, "student n=173")) if base else ((197, "teacher/student n=197"), (99, "student n=99"))):
     M = B * n
-    shapes += [("NT", M, 1152, 384, tag + " qkv"), ("NT", M, 384, 384, tag + " proj"), ("NT", M, 1536, 384, tag + " fc1"),
-               ("NT", M, 384, 1536, tag + " fc2")]
-    if n == 99 or True:
-        shapes += [("NN", M, 1536, 384, tag + " d(fc2)"), ("NN", M, 384, 1536, tag + " d(fc1)"), ("NN", M, 384, 384, tag + " d(proj)"),
-                   ("NN", M, 384, 1152, tag + " d(qkv)"),
-                   ("TN", 384, 1536, M, tag + " wgrad fc2"), ("TN", 1536, 384, M, tag + " wgrad fc1"), ("TN", 384, 384, M, tag + " wgrad proj"),
-                   ("TN", 1152, 384, M, tag + " wgrad qkv")]
-Mp = B * 196
-shapes += [("NT", Mp, 1536, 384, "pred in_conv"), ("NT", Mp, 768, 1536, "pred l0"), ("NT", Mp, 384, 768, "pred l1"),
-           ("NT", Mp, 192, 384, "pred l2"), ("NT", Mp, 96, 192, "pred l3"), ("NT", Mp, 1, 96, "pred l4"),
-           ("NT", Mp, 384, 768, "patch embed"), ("NT", 128, 1000, 384, "head")]
+    shapes += [("NT", M, 3 * D, D, tag + " qkv"), ("NT", M, D, D, tag + " proj"), ("NT", M, 4 * D, D, tag + " fc1"),
+               ("NT", M, D, 4 * D, tag + " fc2")]
+    shapes += [("NN", M, 4 * D, D, tag + " d(fc2)"), ("NN", M, D, 4 * D, tag + " d(fc1)"), ("NN", M, D, D, tag + " d(proj)"),
+               ("NN", M, D, 3 * D, tag + " d(qkv)"),
+               ("TN", D, 4 * D, M, tag + " wgrad fc2"), ("TN", 4 * D, D, M, tag + " wgrad fc1"), ("TN", D, D, M, tag + " wgrad proj"),
+               ("TN", 3 * D, D, M, tag + " wgrad qkv")]
+Mp = B * (576 if base else 196)
+shapes += [("NT", Mp, 4 * D, D, "pred in_conv"), ("NT", Mp, 2 * D, 4 * D, "pred l0"), ("NT", Mp, D, 2 * D, "pred l1"),
+           ("NT", Mp, D // 2, D, "pred l2"), ("NT", Mp, D // 4, D // 2, "pred l3"), ("NT", Mp, 1, D // 4, "pred l4"),
+           ("NT", Mp, D, 768, "patch embed"), ("NT", B, 1000, D, "head")]
 only = os.environ.get("D2S_BENCH_ONLY")     # substring filter on "layout what", e.g. "NT teacher/student n=197 fc1"
 if only:
     shapes = [t for t in shapes if only in f"{t[0]} {t[4]}"]
