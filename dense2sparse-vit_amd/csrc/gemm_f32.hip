@@ -834,6 +834,8 @@ size_t split_workspace_bytes(int split, int M, int N, int K);
 int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace, size_t workspace_bytes, hipStream_t stream);
 size_t split_tn_pieces_bytes(int split, int M, int N, int K);
 int split_tn_colsum_partials(int K);
+bool split_tn_use_dma(int M, int N, int K);
+int split_tn_dma_slices(int M, int N, int K);
 int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_ws, float* colsum_part, hipStream_t stream);
 }
 // Workgroups the wgrad launch aims for (tiles x K slices, rounded down).  Run alone, exactly 2 per CU is best (tools/gemm_bench.py,
@@ -911,8 +913,9 @@ size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K, int mode) {
         return sl > 1 ? (size_t)sl * M * N * sizeof(float) : 0;
     }
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);      // (64x64 wgrad tiles for the small 384x384 weights: measured slower)
-    const int slices = splitk_slices(tiles, K);
+    int slices = splitk_slices(tiles, K);
     size_t bytes = slices <= 1 ? 0 : ((size_t)slices * M * N + (size_t)slices * M) * sizeof(float);   // C slabs + fused bias-gradient slabs
+    if (bf16_wgrad(mode) && split_tn_use_dma(M, N, K)) slices = split_tn_dma_slices(M, N, K);
     if (bf16_wgrad(mode))   // + bf16 pieces of both operands + scratch of the separate bias-gradient pass (see gemm_impl)
         bytes = ws_align(((size_t)(slices + 1) * M * N) * sizeof(float)) + ws_align(split_tn_pieces_bytes(1, M, N, K)) + (size_t)split_tn_colsum_partials(K) * M * sizeof(float);
     return bytes;
@@ -954,10 +957,10 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
         // wgrad in bf16 mode: transposing split of dy and x into K-contiguous bf16 pieces, K-sliced pieces kernel into fp32 slabs,
         // the same ordered slab combine as the exact path; the bias gradient is a separate exact fp32 column-sum pass over dy.
         const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
-        int slices = splitk_slices(tiles, K);
-        const int Kp = ((K + 31) / 32) * 32;
-        int kper = (((Kp + slices - 1) / slices + 31) / 32) * 32;
-        slices = (Kp + kper - 1) / kper;
+        int slices = split_tn_use_dma(M, N, K) ? split_tn_dma_slices(M, N, K) : splitk_slices(tiles, K);
+        const int Kp = ((K + 63) / 64) * 64;
+        int kper = (((Kp + slices - 1) / slices + 63) / 64) * 64;
+        slices = (Kp + kper - 1) / kper;      // never more than the query assumed
         const size_t slab_bytes = ws_align(((size_t)(slices + 1) * M * N) * sizeof(float));
         const size_t piece_bytes = ws_align(split_tn_pieces_bytes(1, M, N, K));
         const size_t cs_bytes = (size_t)split_tn_colsum_partials(K) * M * sizeof(float);

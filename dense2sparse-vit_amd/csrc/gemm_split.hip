@@ -368,6 +368,15 @@ __global__ __launch_bounds__(256, 2) void gemm_pieces_nt_kernel(GemmArgs p, Piec
 //     the buffer goes straight back to the DMA.
 // An LDS-DMA instruction writes wave-uniform base + lane * 16 B, so the LDS image is lane-linear [row][BK bf16]; the bank swizzle
 // (16-byte chunk index XOR row / rows-per-256-B) is applied to the per-lane SOURCE address and again on the fragment read.
+inline int gemm_cus() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return cus;
+}
+
 template <int BK>
 __device__ __forceinline__ int dma_swz(int row) {
     constexpr int CPR = BK / 8, RPB = 256 / (BK * 2);      // 16-byte chunks per row, rows per 256-byte bank row
@@ -392,13 +401,21 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm_bf16_dma_kernel(GemmArgs p,
     const int wm = wave / WGN, wn = wave % WGN;
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     const int nwg = nbm * nbn;
-    int bid = blockIdx.x;
+    // K slices (weight gradients: the reduction runs over tokens): slice z covers k in [z * k_per_slice, ...) and writes its own C slab
+    const int nslices = (q.Kp + p.k_per_slice - 1) / p.k_per_slice;
+    // Persistent workgroups (grid = one residency round): a workgroup walks tiles vb = blockIdx.x, + gridDim.x, ...  The epilogue's
+    // global stores are not waited for, so they drain while the next tile's slabs load and its MFMAs run - otherwise every CU stores
+    // its 256 KB at the same moment (HBM-bound bursts between compute phases, measured 12.7 us of a 32 us tile at K = 768).
+    for (int vb = blockIdx.x; vb < nwg * nslices; vb += gridDim.x) {
+    const int slice = vb / nwg;
+    int bid = vb - slice * nwg;
+    const int kbeg = slice * p.k_per_slice;
+    const int nk = (min(q.Kp, kbeg + p.k_per_slice) - kbeg) / BK;
     {
         const int qq = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
     }
     const int row0 = (bid / nbn) * BM, col0 = (bid % nbn) * BN;
-    const int nk = q.Kp / BK;
 
     // per-lane source byte offsets (K slab 0) of this wave's DMA instructions; rows past the matrix edge re-read the last row (those
     // accumulator rows are never stored)
@@ -418,7 +435,7 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm_bf16_dma_kernel(GemmArgs p,
 
     auto issue = [&](int kt, int buf) {
         unsigned char* st = smem_raw + buf * STAGE;
-        const unsigned kb = (unsigned)kt * RB;
+        const unsigned kb = (unsigned)(kbeg * 2) + (unsigned)kt * RB;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ag + offa[i] + kb),
@@ -507,9 +524,13 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm_bf16_dma_kernel(GemmArgs p,
     mm_head(fa[1], fb[1]);
     mm_tail(fa[1], fb[1]);
 #undef D2S_PIN
-    __syncthreads();      // every wave is done with the operand images: reuse the LDS for the epilogue's wave-private staging
+    // every wave is done with the operand images: reuse the LDS for the epilogue's wave-private staging (raw barrier: nothing to drain)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     float* stage = reinterpret_cast<float*>(smem_raw) + wave * epi_stage_floats(2);
-    store_tile_dispatch_lds<4, 2, true>(p.epi, p, p.C, acc, row0 + wm * 128, col0 + wn * 64, lane, stage);
+    store_tile_dispatch_lds<4, 2, true>(p.epi, p, p.C ? p.C + (long)slice * p.slab_stride : p.C, acc, row0 + wm * 128, col0 + wn * 64, lane, stage);
+    // the next tile's DMA overwrites the staging area: wait for every wave's staging reads (not for the global stores)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
 }
 
 template <int WGN, int BK, int NS>
@@ -523,8 +544,11 @@ inline void launch_dma(const GemmArgs& pv, const PieceArgs& q, hipStream_t strea
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WGN, BK, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const int tiles = ((pv.M + 255) / 256) * ((pv.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_bf16_dma_kernel<WGN, BK, NS>), dim3(tiles), dim3(WGN * 128), lds, stream, pv, q);
+    const int tiles = ((pv.M + 255) / 256) * ((pv.N + BN - 1) / BN) * ((q.Kp + pv.k_per_slice - 1) / pv.k_per_slice);
+    static const int persist_env = [] { const char* e = getenv("D2S_DMA_PERSISTENT"); return e ? atoi(e) : 1; }();
+    const int resident = gemm_cus() * (WGN == 4 ? 1 : 2);      // one 256x256 or two 256x128 workgroups per CU
+    const int grid = (persist_env && tiles > resident) ? resident : tiles;
+    hipLaunchKernelGGL((gemm_bf16_dma_kernel<WGN, BK, NS>), dim3(grid), dim3(WGN * 128), lds, stream, pv, q);
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -566,11 +590,7 @@ int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace,
         if (Kp % 64 == 0 && p.N >= 256) {
             // residency rounds of each grid (256 CUs; one 256x256 or two 256x128 workgroups per CU) x relative cost of a tile
             const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256), t128 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
-            static const int cus = [] {
-                int dev = 0, n = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-                return n;
-            }();
+            const int cus = gemm_cus();
             // cost in units of one 256x256 tile time: a CU runs one 256x256 workgroup or two 256x128 ones (measured 1.17x the time of
             // one 256x256 for the pair, 0.62x when it has a single one)
             const long f128 = t128 / (2 * cus), r128 = t128 % (2 * cus);
@@ -630,13 +650,31 @@ int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace,
 // wgrad on the bf16 matrix cores (mode 2): C slabs[z][M][N] = A^T B over K slice z, with A given as [K][M] and B as [K][N] (both
 // token-major).  Both operands go through the transposing split pass, so the matrix kernel sees K-contiguous pieces as usual.
 // The caller (gemm_f32.hip) combines the slabs in slab order.  Workspace: pieces only (the slabs are the caller's).
-size_t split_tn_pieces_bytes(int split, int M, int N, int K) { return split_workspace_bytes(split, M, N, K); }
+// The pieces are [rows][Kp] with Kp = K rounded up to 64 (zero padded), so that either matrix kernel can slice them.
+static inline int tn_kp(int K) { return ((K + 63) / 64) * 64; }
+size_t split_tn_pieces_bytes(int split, int M, int N, int K) {
+    return align256((size_t)split * M * tn_kp(K) * sizeof(__bf16)) + align256((size_t)split * N * tn_kp(K) * sizeof(__bf16));
+}
+// 256x256 LDS-DMA tiles for weight gradients whose output fills them (every DeiT-S / DeiT-B Linear; not the predictor's narrow layers)
+bool split_tn_use_dma(int M, int N, int K) {
+    static const int env = [] { const char* e = getenv("D2S_SPLIT_DMA_TN"); return e ? atoi(e) : 1; }();
+    const long padded = (long)((M + 255) / 256) * 256 * ((N + 255) / 256) * 256;
+    return env && M >= 256 && N >= 256 && K >= 2048 && padded * 5 <= (long)M * N * 6;      // at most 20 % of the tile area past the edges
+}
+// K slices for the LDS-DMA form: about one 256x256 workgroup per CU, at least 8 slabs of 64 per slice
+int split_tn_dma_slices(int M, int N, int K) {
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    int slices = (gemm_cus() + tiles / 2) / tiles;
+    const int max_slices = tn_kp(K) / 512;
+    if (slices > max_slices) slices = max_slices;
+    return slices < 1 ? 1 : slices;
+}
 
 // colsum_part (optional, [split_tn_colsum_partials(K)][M] floats): per-64-token partial column sums of A (= dy), produced by the split
 // pass that reads dy anyway; the caller folds them in order into the bias gradient.
-int split_tn_colsum_partials(int K) { return (((K + 31) / 32) * 32 + 63) / 64; }
+int split_tn_colsum_partials(int K) { return tn_kp(K) / 64; }
 int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_ws, float* colsum_part, hipStream_t stream) {
-    const int Kp = ((p.K + 31) / 32) * 32;
+    const int Kp = tn_kp(p.K);
     if (split != 1) return D2S_ERR_ARG;
     if ((long)p.M * Kp * 2 >= (1L << 32) || (long)p.N * Kp * 2 >= (1L << 32)) return D2S_ERR_ARG;
     __bf16* Ap = static_cast<__bf16*>(pieces_ws);
@@ -644,12 +682,17 @@ int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_
     dim3 block(256);
     hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.M + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA, colsum_part);
     hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB, static_cast<float*>(nullptr));
+    GemmArgs pv = p;                      // p.C / p.ldc / p.slab_stride / p.k_per_slice / p.epi were set by the caller
+    pv.vec_epilogue = (epilogue_vec_ok(p) && (p.slab_stride % 4 == 0)) ? 1 : 0;
+    pv.a16 = nullptr; pv.c16 = nullptr;
+    PieceArgs q{Ap, Bp, Kp};
+    if (split_tn_use_dma(p.M, p.N, p.K) && pv.vec_epilogue && p.k_per_slice % 64 == 0) {
+        launch_dma<4, 64, 2>(pv, q, stream);
+        return d2s_check_launch();
+    }
     const int tiles = ((p.M + SBM - 1) / SBM) * ((p.N + SBN - 1) / SBN);
     size_t lds = (size_t)split * (SBM + SBN) * (32 + 8) * sizeof(__bf16);
     if (lds < 4 * epi_stage_floats(2) * sizeof(float)) lds = 4 * epi_stage_floats(2) * sizeof(float);
-    GemmArgs pv = p;                      // p.C / p.ldc / p.slab_stride / p.k_per_slice / p.epi were set by the caller
-    pv.vec_epilogue = (epilogue_vec_ok(p) && (p.slab_stride % 4 == 0)) ? 1 : 0;
-    PieceArgs q{Ap, Bp, Kp};
     hipLaunchKernelGGL((gemm_pieces_nt_kernel<1, 32, false>), dim3(tiles, 1, slices), block, lds, stream, pv, q);
     return d2s_check_launch();
 }

@@ -435,10 +435,12 @@ def test_attn_fwd_bf16out(ops):
         ops.set_gemm_mode(0)
 
 
-@pytest.mark.parametrize("tokens,n_out,n_in", [(197 * 8, 384, 1536), (1000, 96, 192), (130, 10, 24), (4100, 200, 72)])
+@pytest.mark.parametrize("tokens,n_out,n_in", [(197 * 8, 384, 1536), (1000, 96, 192), (130, 10, 24), (4100, 200, 72),
+                                               (5000, 768, 768), (9991, 512, 1024), (2100, 3072, 768)])
 def test_linear_wgrad_bf16_mode(ops, tokens, n_out, n_in):
-    """Mode 2 runs the weight gradient on the bf16 matrix cores (transposing split + K-sliced pieces kernel + ordered combine);
-    the bias gradient stays an exact fp32 column sum.  Tolerance: bf16 operand rounding (2^-9 relative per product)."""
+    """Mode 2 runs the weight gradient on the bf16 matrix cores (transposing split + K-sliced matrix kernel - the 256x256 LDS-DMA kernel
+    where the weight fills its tiles, last three shapes - + ordered combine); the bias gradient stays an exact fp32 column sum.
+    Tolerance: bf16 operand rounding (2^-9 relative per product)."""
     g = torch.Generator().manual_seed(tokens + n_in)
     dy = torch.randn(tokens, n_out, generator=g)
     x = torch.randn(tokens, n_in, generator=g)
