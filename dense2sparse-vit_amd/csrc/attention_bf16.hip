@@ -231,7 +231,8 @@ __device__ __forceinline__ f32x16 mma_rows(const __bf16* __restrict__ S, const b
     }
     return acc;
 }
-__device__ __forceinline__ void store_t(const f32x16 (&acc)[2], float* __restrict__ p, int half, float mul) {     // acc^T -> one row of 64 d
+// acc^T -> one row of 64 d (at element offset `off` of p, and of the optional bf16 copy p16)
+__device__ __forceinline__ void store_t(const f32x16 (&acc)[2], float* __restrict__ p, __bf16* __restrict__ p16, long off, int half, float mul) {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -239,14 +240,21 @@ __device__ __forceinline__ void store_t(const f32x16 (&acc)[2], float* __restric
             f32x4 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = acc[dt][4 * g + j] * mul;
-            *reinterpret_cast<f32x4*>(p + 32 * dt + 8 * g + 4 * half) = v;
+            *reinterpret_cast<f32x4*>(p + off + 32 * dt + 8 * g + 4 * half) = v;
+            if (p16) {
+                typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                bf16x4_t hv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hv[j] = (__bf16)v[j];
+                *reinterpret_cast<bf16x4_t*>(p16 + off + 32 * dt + 8 * g + 4 * half) = hv;
+            }
         }
 }
 
 // ---- backward, dQ: a lane owns one query; loop over key tiles (S^T, dP^T, dS^T lane-local, dQ^T = K^T dS^T) ------------------------
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                  float* __restrict__ dqkv, int n, int H, float scale) {
+                                                                  float* __restrict__ dqkv, __bf16* __restrict__ dqkv16, int n, int H, float scale) {
     __shared__ __attribute__((aligned(16))) __bf16 Ks[32 * KP];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[32 * KP];
     __shared__ __attribute__((aligned(16))) __bf16 Kt[DH * VP];
@@ -293,13 +301,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const float* _
         pack2(s, pf);
         mma_t(Kt, pf, l31, half, dq);                    // dQ^T[d][query] += sum_key K[key][d] dS^T[key][query]
     }
-    if (active && qok) store_t(dq, dqkv + ((long)b * n + q0 + l31) * ld + h * DH, half, scale);
+    if (active && qok) store_t(dq, dqkv, dqkv16, ((long)b * n + q0 + l31) * ld + h * DH, half, scale);
 }
 
 // ---- backward, dK / dV: a lane owns one key; loop over query tiles ------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                    const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                   float* __restrict__ dqkv, int n, int H, float scale) {
+                                                                   float* __restrict__ dqkv, __bf16* __restrict__ dqkv16, int n, int H, float scale) {
     __shared__ __attribute__((aligned(16))) __bf16 Qs[32 * KP];
     __shared__ __attribute__((aligned(16))) __bf16 Ds[32 * KP];
     __shared__ __attribute__((aligned(16))) __bf16 Qt[DH * VP];
@@ -360,9 +368,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const float* 
         mma_t(Qt, dsf, l31, half, dk);                   // dK^T[d][key] += sum_query Q[query][d] dS[query][key]
     }
     if (active && kok) {
-        float* row = dqkv + ((long)b * n + k0 + l31) * ld + h * DH;
-        store_t(dk, row + (long)H * DH, half, scale);
-        store_t(dv, row + 2L * H * DH, half, 1.0f);
+        const long row = ((long)b * n + k0 + l31) * ld + h * DH;
+        store_t(dk, dqkv, dqkv16, row + (long)H * DH, half, scale);
+        store_t(dv, dqkv, dqkv16, row + 2L * H * DH, half, 1.0f);
     }
 }
 
@@ -394,15 +402,25 @@ int d2s_attn_fwd_bf16_bf16out(const float* qkv, float* out, void* out_bf16, floa
 int d2s_attn_delta(const float* out, const float* dout, float* delta, int B, int n, int H, hipStream_t stream);
 
 // Backward of the same mode (same contract as d2s_attn_bwd_f32): dqkv [B,n,3,H,64] fully written; delta_ws: [B,H,n] floats of scratch.
-int d2s_attn_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws, int B, int n,
-                      int H, float scale, hipStream_t stream) {
+static int attn_bwd_bf16_impl(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, __bf16* dqkv16,
+                              float* delta_ws, int B, int n, int H, float scale, hipStream_t stream) {
     if (!qkv || !out || !dout || !lse || !dqkv || !delta_ws || B <= 0 || n <= 0 || H <= 0) return D2S_ERR_ARG;
     const int rc = d2s_attn_delta(out, dout, delta_ws, B, n, H, stream);
     if (rc != D2S_OK) return rc;
     dim3 grid((n + 127) / 128, B * H), block(256);
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, n, H, scale);
-    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, n, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, dqkv16, n, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, dqkv16, n, H, scale);
     return d2s_check_launch();
+}
+int d2s_attn_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws, int B, int n,
+                      int H, float scale, hipStream_t stream) {
+    return attn_bwd_bf16_impl(qkv, out, dout, lse, dqkv, nullptr, delta_ws, B, n, H, scale, stream);
+}
+// ... with a bf16 copy of dqkv (same [B,n,3,H,64] layout): the a_bf16 of the qkv Linear's input-gradient GEMM
+int d2s_attn_bwd_bf16_bf16out(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, void* dqkv_bf16,
+                              float* delta_ws, int B, int n, int H, float scale, hipStream_t stream) {
+    if (!dqkv_bf16) return D2S_ERR_ARG;
+    return attn_bwd_bf16_impl(qkv, out, dout, lse, dqkv, static_cast<__bf16*>(dqkv_bf16), delta_ws, B, n, H, scale, stream);
 }
 
 }  // extern "C"

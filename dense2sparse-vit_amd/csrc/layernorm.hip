@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ w, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, float* __restrict__ dx, RowMap dxm,
                                                      const float* __restrict__ add_src, float* __restrict__ part,
-                                                     long rows, int D, long rows_per_block, int relu_mask) {
+                                                     long rows, int D, long rows_per_block, int relu_mask, __bf16* __restrict__ dx16) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [3][2][D]  (waves 1..3)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = D >> 2;
@@ -233,6 +233,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                     for (int j = 0; j < 4; ++j) o[j] += a[j];
                 }
                 *reinterpret_cast<f32x4*>(dx + doff + c * 4) = o;
+                if (dx16) store_bf16x4(dx16 + row * D + c * 4, o);      // dense bf16 copy: the A operand of the next input-gradient GEMM
             }
         }
     };
@@ -445,10 +446,10 @@ size_t d2s_layernorm_bwd_workspace_bytes(long rows, int D) { return (size_t)bwd_
 // null).  relu_mask != 0: mask = (x > 0), i.e. the backward of a ReLU whose OUTPUT is this LayerNorm's input
 // (the predictor's Linear->ReLU->LayerNorm chain, dynamic_vit.py:515-528), folded into the same pass.
 // x and dx/add_src share one RowMap; dy, mean, rstd are contiguous per logical row.
-int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* dy,
-                      const float* w, const float* mean, const float* rstd, float* dx, const float* add_src, float* dweight,
-                      float* dbias, int accumulate_wb, int relu_mask, long rows, int D, void* workspace,
-                      size_t workspace_bytes, hipStream_t stream) {
+static int layernorm_bwd_impl(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* dy,
+                              const float* w, const float* mean, const float* rstd, float* dx, __bf16* dx16, const float* add_src, float* dweight,
+                              float* dbias, int accumulate_wb, int relu_mask, long rows, int D, void* workspace,
+                              size_t workspace_bytes, hipStream_t stream) {
     if (!x || !dy || !w || !mean || !rstd || !dx || rows <= 0 || D <= 0 || D > 4096) return D2S_ERR_ARG;
     const bool scalar = (D & 3) || ((group_stride | row_stride | offset) & 3);
     const int nb = bwd_blocks(rows);
@@ -464,6 +465,7 @@ int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, lo
     dim3 grid(nblocks), block(256);
     const size_t sh = (size_t)3 * 2 * D * sizeof(float);
     if (scalar) {
+        if (dx16) return D2S_ERR_ARG;      // the bf16 copy exists for the vector kernels only (D % 4 == 0)
         hipLaunchKernelGGL(ln_bwd_scalar_kernel, grid, block, (size_t)4 * 2 * D * sizeof(float), stream, x, m, dy, w, mean, rstd, dx,
                            add_src, part, rows, D, rpb, relu_mask);
         if (dweight)
@@ -471,7 +473,7 @@ int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, lo
                                accumulate_wb);
         return d2s_check_launch();
     }
-#define D2S_LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, sh, stream, x, m, dy, w, mean, rstd, dx, m, add_src, part, rows, D, rpb, relu_mask)
+#define D2S_LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, sh, stream, x, m, dy, w, mean, rstd, dx, m, add_src, part, rows, D, rpb, relu_mask, dx16)
     switch (pick_nv(D)) {
         case 1: D2S_LN_BWD(1); break;
         case 2: D2S_LN_BWD(2); break;
@@ -484,6 +486,25 @@ int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, lo
         hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * D + FOLD_COLS - 1) / FOLD_COLS), dim3(FOLD_COLS * FOLD_LANES), 0, stream, part, nblocks, D, dweight, dbias,
                            accumulate_wb);
     return d2s_check_launch();
+}
+
+int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* dy,
+                      const float* w, const float* mean, const float* rstd, float* dx, const float* add_src, float* dweight,
+                      float* dbias, int accumulate_wb, int relu_mask, long rows, int D, void* workspace,
+                      size_t workspace_bytes, hipStream_t stream) {
+    return layernorm_bwd_impl(x, rows_per_group, group_stride, row_stride, offset, dy, w, mean, rstd, dx, nullptr, add_src, dweight, dbias,
+                              accumulate_wb, relu_mask, rows, D, workspace, workspace_bytes, stream);
+}
+
+// The same backward with a dense [rows, D] bf16 copy of dx (after the residual add): the a_bf16 of the input-gradient GEMM that consumes
+// it in the bf16 mode.  D % 4 == 0.
+int d2s_layernorm_bwd_bf16out(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* dy,
+                              const float* w, const float* mean, const float* rstd, float* dx, void* dx_bf16, const float* add_src,
+                              float* dweight, float* dbias, int accumulate_wb, int relu_mask, long rows, int D, void* workspace,
+                              size_t workspace_bytes, hipStream_t stream) {
+    if (!dx_bf16) return D2S_ERR_ARG;
+    return layernorm_bwd_impl(x, rows_per_group, group_stride, row_stride, offset, dy, w, mean, rstd, dx, static_cast<__bf16*>(dx_bf16), add_src,
+                              dweight, dbias, accumulate_wb, relu_mask, rows, D, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

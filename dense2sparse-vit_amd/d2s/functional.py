@@ -145,6 +145,7 @@ class BlockFn(torch.autograd.Function):
         # multiplies, and that GEMM reads it instead of converting its fp32 operand (no conversion passes on the forward path)
         io = ops.bf16_io() and D % 32 == 0 and hidden % 32 == 0 and x.is_cuda
         io_attn = io and policy is None and ops._BF16_ATTENTION
+        ops._SHADOW.clear()          # gradient shadows never outlive the backward pass that made them
         if not any(ctx.needs_input_grad):
             # forward-only (the frozen teacher under no_grad, eval): no LayerNorm statistics, no GELU pre-activation copy (155 MB per
             # block at B=128), nothing saved; on the bf16 data path not even the fp32 form of the GEMM inputs
@@ -237,34 +238,50 @@ class BlockFn(torch.autograd.Function):
 
         # ---- MLP branch ----
         grads[11], grads[12] = ops.linear_param_grads(gy, h, fc2w, fc2b, wants[11], wants[12])
-        dzh = ops.bf16_buffer(M, z.shape[1], dev) if (ops.bf16_io() and z.shape[1] % 32 == 0 and D % 32 == 0 and gy.is_cuda) else None
-        dz = ops.linear_dgrad(gy, fc2w, epi=ops.EPI_MUL_GELU_GRAD, aux=z, c16=dzh)
+        # bf16 data path: every gradient that feeds an input-gradient GEMM is also produced in bf16 by the kernel that computes it
+        io = ops.bf16_io() and z.shape[1] % 32 == 0 and D % 32 == 0 and gy.is_cuda
+        policy, cinv = ctx.policy
+        io_attn = io and policy is None and ops._BF16_ATTENTION
+        gyh = ops.shadow_take(gy) if io else None
+        if gyh is not None:
+            gyh = gyh.view(M, D)
+        dzh = ops.bf16_buffer(M, z.shape[1], dev) if io else None
+        dz = ops.linear_dgrad(gy, fc2w, epi=ops.EPI_MUL_GELU_GRAD, aux=z, a16=gyh, c16=dzh)
+        del gyh
         grads[9], grads[10] = ops.linear_param_grads(dz, ln2, fc1w, fc1b, wants[9], wants[10])
         dln2 = ops.linear_dgrad(dz, fc1w, a16=dzh)
         del dzh
         g1 = torch.empty((M, D), dtype=torch.float32, device=dev)
+        g1h = ops.bf16_buffer(M, D, dev) if io else None
         dn2w = new(n2w) if (wants[7] or wants[8]) else None
         dn2b = new(n2b) if dn2w is not None else None
-        ops.layernorm_bwd(x1, cmap, dln2, n2w, mean2, rstd2, g1, gy, dn2w, dn2b, M, D)
+        ops.layernorm_bwd(x1, cmap, dln2, n2w, mean2, rstd2, g1, gy, dn2w, dn2b, M, D, dx16=g1h)
         grads[7], grads[8] = (dn2w if wants[7] else None), (dn2b if wants[8] else None)
         # ---- attention branch ----
         grads[5], grads[6] = ops.linear_param_grads(g1, ao, projw, projb, wants[5], wants[6])
-        dao = ops.linear_dgrad(g1, projw)
-        policy, cinv = ctx.policy
+        dao = ops.linear_dgrad(g1, projw, a16=g1h)
+        del g1h
+        dqkvh = None
         if policy is None:
-            dqkv = ops.attn_bwd(qkv, ao, dao, lse, B, n, heads, scale)
+            if io_attn:
+                dqkvh = torch.empty(qkv.shape, dtype=torch.bfloat16, device=dev)
+            dqkv = ops.attn_bwd(qkv, ao, dao, lse, B, n, heads, scale, dqkv16=dqkvh)
         else:
             dqkv = ops.attn_policy_bwd(qkv, policy, ao, dao, lse, cinv, B, n, heads, scale)
         grads[3], grads[4] = ops.linear_param_grads(dqkv, ln1, qkvw, qkvb, wants[3], wants[4])
         gx = None
         if wants[0] or wants[1] or wants[2]:
-            dln1 = ops.linear_dgrad(dqkv, qkvw)
+            dln1 = ops.linear_dgrad(dqkv, qkvw, a16=dqkvh)
+            del dqkvh
             gx = torch.empty((M, D), dtype=torch.float32, device=dev)
+            gxh = ops.bf16_buffer(M, D, dev) if (io and wants[0]) else None
             dn1w = new(n1w) if (wants[1] or wants[2]) else None
             dn1b = new(n1b) if dn1w is not None else None
-            ops.layernorm_bwd(x, cmap, dln1, n1w, mean1, rstd1, gx, g1, dn1w, dn1b, M, D)
+            ops.layernorm_bwd(x, cmap, dln1, n1w, mean1, rstd1, gx, g1, dn1w, dn1b, M, D, dx16=gxh)
             grads[1], grads[2] = (dn1w if wants[1] else None), (dn1b if wants[2] else None)
             gx = gx.view(B, n, D) if wants[0] else None
+            if gxh is not None:
+                ops.shadow_put(gx, gxh)
         grads[0] = gx
         return tuple(grads) + (None, None, None, None) + (None,) * ctx.nextra
 

@@ -32,6 +32,7 @@ _SIGS = {
     "d2s_layernorm_fwd_bf16out": (I, [P, L, L, L, L, P, P, P, P, P, P, L, I, F]),
     "d2s_layernorm_bwd_workspace_bytes": (Z, [L, I]),
     "d2s_layernorm_bwd": (I, [P, L, L, L, L, P, P, P, P, P, P, P, P, I, I, L, I, P, Z]),
+    "d2s_layernorm_bwd_bf16out": (I, [P, L, L, L, L, P, P, P, P, P, P, P, P, P, I, I, L, I, P, Z]),
     "d2s_softmax_rows": (I, [P, P, I, I]),
     "d2s_select_topk": (I, [P, I, I, I, P, P]),
     "d2s_gather_pack_fwd": (I, [P, P, P, I, I, I, I]),
@@ -54,6 +55,7 @@ _SIGS = {
     "d2s_attn_fwd_bf16_bf16out": (I, [P, P, P, P, P, I, I, I, F]),
     "d2s_attn_bwd_f32": (I, [P, P, P, P, P, P, I, I, I, F]),
     "d2s_attn_bwd_bf16": (I, [P, P, P, P, P, P, I, I, I, F]),
+    "d2s_attn_bwd_bf16_bf16out": (I, [P, P, P, P, P, P, P, I, I, I, F]),
     "d2s_attn_delta": (I, [P, P, P, I, I, I]),
     "d2s_attn_bwd_dq_f32": (I, [P, P, P, P, P, I, I, I, F]),
     "d2s_attn_bwd_dkv_f32": (I, [P, P, P, P, P, I, I, I, F]),

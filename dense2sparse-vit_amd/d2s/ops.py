@@ -47,6 +47,30 @@ def bf16_buffer(rows, cols, device):
     return torch.empty((rows, cols), dtype=torch.bfloat16, device=device)
 
 
+# A gradient that leaves one autograd Function and enters the next (a block's dx = the previous block's dy) cannot carry its bf16 copy
+# through autograd; the producer parks it here under the fp32 tensor's address and the consumer takes it out again.  An entry is used at
+# most once and only if address, element count and the version counter of the fp32 tensor still match (anything that rewrote or replaced
+# the gradient in between - an accumulation, a hook, the token scatter at a pruning stage - makes the lookup miss, and the consumer
+# converts the fp32 gradient itself).
+_SHADOW = {}
+shadow_hits = 0                           # diagnostic: how many gradients found their bf16 copy (tests assert the path is taken)
+
+
+def shadow_put(t, t16):
+    _SHADOW.clear()                       # at most one gradient is in flight between two blocks
+    _SHADOW[t.data_ptr()] = (t.numel(), t._version, t16)
+
+
+def shadow_take(t):
+    e = _SHADOW.pop(t.data_ptr(), None)
+    _SHADOW.clear()
+    if e is None or e[0] != t.numel() or e[1] != t._version:
+        return None
+    global shadow_hits
+    shadow_hits += 1
+    return e[2]
+
+
 def gemm(layout, A, lda, B, ldb, C, ldc, M, N, K, epi=EPI_NONE, bias=None, aux=None, ldaux=0, aux_out=None, aux_rows=0,
          remap_rows=0, remap_skip=0, accumulate=False, a16=None, c16=None):
     mode = get_gemm_mode()
@@ -300,9 +324,15 @@ def layernorm_fwd_bf16(x, rowmap, w, b, rows, D, eps, stats=True, want_f32=True)
     return y, mean, rstd, y16
 
 
-def layernorm_bwd(x, rowmap, dy, w, mean, rstd, dx, add_src, dw, db, rows, D, accumulate_wb=False, relu_mask=False):
+def layernorm_bwd(x, rowmap, dy, w, mean, rstd, dx, add_src, dw, db, rows, D, accumulate_wb=False, relu_mask=False, dx16=None):
+    """dx16 (bf16 mode): dense bf16 [rows, D] buffer that receives a copy of dx."""
     need = lib.query("d2s_layernorm_bwd_workspace_bytes", rows, D)
     ws = workspace(need, dy.device)
+    if dx16 is not None:
+        assert dx16.dtype == torch.bfloat16 and dx16.is_contiguous() and tuple(dx16.shape) == (rows, D)
+        lib.call("d2s_layernorm_bwd_bf16out", lib.ptr(x), *rowmap, lib.ptr(dy), lib.ptr(w), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dx),
+                 lib.ptr(dx16), lib.ptr(add_src), lib.ptr(dw), lib.ptr(db), int(accumulate_wb), int(relu_mask), rows, D, lib.ptr(ws), ws.numel())
+        return dx
     lib.call("d2s_layernorm_bwd", lib.ptr(x), *rowmap, lib.ptr(dy), lib.ptr(w), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dx),
              lib.ptr(add_src), lib.ptr(dw), lib.ptr(db), int(accumulate_wb), int(relu_mask), rows, D, lib.ptr(ws), ws.numel())
     return dx
@@ -458,10 +488,16 @@ def attn_fwd_bf16io(qkv, B, n, H, scale, want_cls=True, want_f32=True):
     return out, lse, cls_row, out16
 
 
-def attn_bwd(qkv, out, dout, lse, B, n, H, scale):
+def attn_bwd(qkv, out, dout, lse, B, n, H, scale, dqkv16=None):
+    """dqkv16 (bf16 mode with the bf16 attention kernels): bf16 buffer shaped like qkv that receives a copy of dqkv."""
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device)
     bf16 = get_gemm_mode() == GEMM_BF16 and _BF16_ATTENTION
+    if dqkv16 is not None:
+        assert bf16 and dqkv16.dtype == torch.bfloat16 and dqkv16.is_contiguous() and dqkv16.numel() == qkv.numel()
+        lib.call("d2s_attn_bwd_bf16_bf16out", lib.ptr(qkv), lib.ptr(out), lib.ptr(dout), lib.ptr(lse), lib.ptr(dqkv), lib.ptr(dqkv16),
+                 lib.ptr(delta), B, n, H, float(scale))
+        return dqkv
     if _WGRAD["on"] and _ATTN_BWD_STREAMS and not bf16 and qkv.is_cuda:
         # inside TrainStep's backward: the dK/dV kernel on a stream of its own beside the dQ kernel (independent, disjoint outputs);
         # both are joined again before anything reads dqkv

@@ -89,6 +89,12 @@ int d2s_layernorm_bwd(const float* x, long rows_per_group, long group_stride, lo
                       float* dbias, int accumulate_wb, int relu_mask, long rows, int D, void* workspace,
                       size_t workspace_bytes, d2s_stream_t stream);
 
+/* the same backward with a dense [rows, D] bf16 copy of dx (after the residual add): the a_bf16 of the input-gradient GEMM that follows */
+int d2s_layernorm_bwd_bf16out(const float* x, long rows_per_group, long group_stride, long row_stride, long offset, const float* dy,
+                              const float* w, const float* mean, const float* rstd, float* dx, void* dx_bf16, const float* add_src,
+                              float* dweight, float* dbias, int accumulate_wb, int relu_mask, long rows, int D, void* workspace,
+                              size_t workspace_bytes, d2s_stream_t stream);
+
 /* ---- fused attention, head dim 64 (vit_models/dynamic_vit.py:218-236; CLS row returned at :234) ------------------
  * qkv: raw output of the qkv Linear, [B, n, 3, H, 64]; out/dout: [B, n, H*64]; lse, cls_row, delta_ws: [B, H, n]. */
 int d2s_attn_fwd_f32(const float* qkv, float* out, float* lse, float* cls_row, int B, int n, int H, float scale,
@@ -113,6 +119,9 @@ int d2s_attn_delta(const float* out, const float* dout, float* delta, int B, int
 /* backward on the bf16 matrix cores (bf16 arithmetic mode), same contract as d2s_attn_bwd_f32 */
 int d2s_attn_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws,
                      int B, int n, int H, float scale, d2s_stream_t stream);
+/* ... with a bf16 copy of dqkv in the same [B,n,3,H,64] layout (the a_bf16 of the qkv Linear's input-gradient GEMM) */
+int d2s_attn_bwd_bf16_bf16out(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, void* dqkv_bf16,
+                              float* delta_ws, int B, int n, int H, float scale, d2s_stream_t stream);
 
 /* Attention.softmax_with_policy (vit_models/dynamic_vit.py:195-214) on materialised scores [B,H,N,N], policy [B,N];
  * the backward includes the path through the row maximum (the reference does not detach it). */

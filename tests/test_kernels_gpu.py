@@ -419,6 +419,38 @@ def test_layernorm_fwd_bf16out(ops, rows, D):
     assert y3 is None and m3 is None and r3 is None and torch.equal(y16b, y16)
 
 
+def test_layernorm_bwd_bf16out(ops):
+    """d2s_layernorm_bwd_bf16out: identical fp32 outputs, bf16 copy = rounding of dx (after the residual add)."""
+    rows, D = 1000, 768
+    x, dy, w = _rand("bx", (rows, D)).to(_dev()), _rand("bdy", (rows, D)).to(_dev()), (_rand("bw", (D,), 0.5) + 1).to(_dev())
+    add = _rand("badd", (rows, D)).to(_dev())
+    cmap = ops.contiguous_map(rows, D)
+    _, mean, rstd = ops.layernorm_fwd(x, cmap, w, torch.zeros(D, device=_dev()), rows, D, 1e-6)
+    dx1, dw1, db1 = torch.empty_like(x), torch.empty(D, device=_dev()), torch.empty(D, device=_dev())
+    ops.layernorm_bwd(x, cmap, dy, w, mean, rstd, dx1, add, dw1, db1, rows, D)
+    dx2, dw2, db2 = torch.empty_like(x), torch.empty(D, device=_dev()), torch.empty(D, device=_dev())
+    dx16 = torch.empty((rows, D), dtype=torch.bfloat16, device=_dev())
+    ops.layernorm_bwd(x, cmap, dy, w, mean, rstd, dx2, add, dw2, db2, rows, D, dx16=dx16)
+    assert torch.equal(dx1, dx2) and torch.equal(dw1, dw2) and torch.equal(db1, db2)
+    assert torch.equal(dx16, dx1.bfloat16())
+
+
+def test_attn_bwd_bf16out(ops):
+    """d2s_attn_bwd_bf16_bf16out: same dqkv as d2s_attn_bwd_bf16 and its bf16 rounding."""
+    B, n, H = 2, 197, 6
+    qkv = _rand("bq", (B * n, 3 * H * 64), 0.5).to(_dev())
+    dout = _rand("bdo", (B * n, H * 64), 0.5).to(_dev())
+    ops.set_gemm_mode(2)
+    try:
+        out, lse, _ = ops.attn_fwd(qkv, B, n, H, 0.125, False)
+        d1 = ops.attn_bwd(qkv, out, dout, lse, B, n, H, 0.125)
+        d16 = torch.empty(qkv.shape, dtype=torch.bfloat16, device=_dev())
+        d2 = ops.attn_bwd(qkv, out, dout, lse, B, n, H, 0.125, dqkv16=d16)
+        assert torch.equal(d1, d2) and torch.equal(d16, d1.bfloat16())
+    finally:
+        ops.set_gemm_mode(0)
+
+
 def test_attn_fwd_bf16out(ops):
     """d2s_attn_fwd_bf16_bf16out: same fp32 outputs as d2s_attn_fwd_bf16, bf16 copy = rounding of the output, and the bf16-only form."""
     B, n, H = 3, 197, 6

@@ -479,7 +479,9 @@ def test_bf16_data_path_full_size_matches_per_call_conversion():
             ops._BF16_IO = saved
         return outs, names, ts
 
+    hits0 = ops.shadow_hits
     on, names, ts_on = step(True, None, 2)
+    assert ops.shadow_hits - hits0 >= 2 * 8, "block-to-block gradients did not find their bf16 copies"      # 11 block boundaries, one of them a pruning stage
     assert torch.equal(on[0][0], on[1][0]) and torch.equal(on[0][2], on[1][2]) and torch.equal(on[0][4], on[1][4]), "bf16 data path is not deterministic"
     assert torch.isfinite(on[0][4]).all() and float(on[0][4].abs().max()) > 0
     kept = on[0][1].cpu()
