@@ -37,7 +37,9 @@ GEMM_MODE_ROOFLINE = {
     "exact": ("gemm_f32_kernel", "v_mfma_f32_32x32x2_f32", PEAK_F32_MFMA_TFLOPS),
     # bf16x3 split: 6 bf16 MFMAs per fp32-class product -> the algorithmic ceiling is a sixth of the bf16 peak
     "split": ("gemm_pieces_nt_kernel<3 pieces>", "v_mfma_f32_32x32x16_bf16 x6 per product", PEAK_BF16_MFMA_TFLOPS / 6.0),
-    "bf16": ("gemm_pieces_nt_kernel<1 piece>", "v_mfma_f32_32x32x16_bf16", PEAK_BF16_MFMA_TFLOPS),
+    # large shapes run in the LDS-DMA kernel (256x256 / 256x128 tiles), small ones in the 128x128 pieces kernel; the figure is the whole C-ABI
+    # call, i.e. it includes the weight's bf16 conversion pass and, where the caller has no bf16 copy of the activation, that conversion too
+    "bf16": ("gemm_bf16_dma_kernel (+ gemm_pieces_nt_kernel<1 piece> on small shapes, conversion passes included)", "v_mfma_f32_32x32x16_bf16", PEAK_BF16_MFMA_TFLOPS),
 }
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 
@@ -139,6 +141,9 @@ class KernelTimer:
                                   lambda x, rowmap, dy, w, mean, rstd, dx, add_src, dw, db, rows, D, *a, **kw:
                                   rows * D * 4.0 * (3 + (1 if add_src is not None else 0)))
         ops.layernorm_fwd = timed(ops.layernorm_fwd, ("layernorm_fwd", ""), lambda x, rowmap, w, b, rows, D, eps, **kw: rows * D * 8.0)
+        # bf16 data path: read fp32, write the bf16 copy (+ the fp32 result unless want_f32=False)
+        ops.layernorm_fwd_bf16 = timed(ops.layernorm_fwd_bf16, ("layernorm_fwd", ""),
+                                       lambda x, rowmap, w, b, rows, D, eps, stats=True, want_f32=True: rows * D * (10.0 if want_f32 else 6.0))
         ops.adamw_step = timed(ops.adamw_step, ("adamw", ""), lambda params, *a, **kw: params.numel() * 28.0)
 
         orig_wgrad = ops.linear_wgrad
@@ -449,7 +454,7 @@ def main():
             assert ach <= peak, f"achieved {ach:.1f} TFLOP/s above the {peak} peak: wrong peak or wrong FLOP count"
             # NT / NN run in the [row][k]-image kernel (template argument = B layout), TN (wgrad) in the [k][row]-image kernel
             pmc_prefix = {"NT": "gemm_f32_rk_kernel<0,", "NN": "gemm_f32_rk_kernel<1,", "TN": "gemm_f32_kernel<1, 1,"}[dom[1]] if mode_key == "exact" \
-                else "gemm_pieces_nt_kernel"
+                else ("gemm_bf16_dma_kernel" if mode_key == "bf16" else "gemm_pieces_nt_kernel")
             if mode_key == "exact" and dom[1] != "TN":
                 kern = "gemm_f32_rk_kernel"
             line["roofline"] = {"bound": "mfma", "kernel": f"{kern}, {dom[1]} layout ({instr})",

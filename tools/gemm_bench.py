@@ -44,14 +44,22 @@ for L, M, N, K, what in shapes:
     C = torch.empty(M, N, device=dev)
     bias = torch.randn(N, device=dev)
     epi = ops.EPI_BIAS if L == "NT" else ops.EPI_NONE
+    kw = {}
+    io = os.environ.get("D2S_BENCH_IO", "0")      # bf16 mode: 1 = A given in bf16, 2 = also a bf16 copy of C, 3 = bf16 copy only (no fp32 C)
+    if io != "0" and mode == 2 and L != "TN":
+        kw["a16"] = A.bfloat16()
+        if io in ("2", "3"):
+            kw["c16"] = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        if io == "3":
+            C = None
     for _ in range(3):
-        ops.gemm(lay[L], A, lda, Bm, ldb, C, N, M, N, K, epi, bias)
+        ops.gemm(lay[L], A, lda, Bm, ldb, C, N, M, N, K, epi, bias, **kw)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     it = 20
     s.record()
     for _ in range(it):
-        ops.gemm(lay[L], A, lda, Bm, ldb, C, N, M, N, K, epi, bias)
+        ops.gemm(lay[L], A, lda, Bm, ldb, C, N, M, N, K, epi, bias, **kw)
     e.record(); torch.cuda.synchronize()
     us = s.elapsed_time(e) * 1000 / it
     print(f"{L:6} {M:6d} {N:5d} {K:6d}  {us:8.1f} {2.0*M*N*K/us/1e6:7.1f}  {what}")
