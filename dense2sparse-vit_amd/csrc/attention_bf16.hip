@@ -28,7 +28,20 @@ __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, co
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+// 8 consecutive values of a q / k / v row as fp32, from the fp32 qkv tensor or from its bf16 form (the qkv GEMM's c_bf16: the same
+// values this kernel would round to itself, so both inputs give identical results)
+__device__ __forceinline__ void load8(const float* __restrict__ p, f32x4 (&r)[2]) {
+    r[0] = *reinterpret_cast<const f32x4*>(p);
+    r[1] = *reinterpret_cast<const f32x4*>(p + 4);
+}
+__device__ __forceinline__ void load8(const __bf16* __restrict__ p, f32x4 (&r)[2]) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { r[0][j] = (float)v[j]; r[1][j] = (float)v[4 + j]; }
+}
+
+template <typename QT>
+__global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const QT* __restrict__ qkv, float* __restrict__ out,
                                                                __bf16* __restrict__ out16, float* __restrict__ lse, float* __restrict__ cls_row, int n, int H,
                                                                float scale) {
     __shared__ __attribute__((aligned(16))) __bf16 Ks[32 * KP];      // [key][d]
@@ -37,9 +50,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const float* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y / H, h = blockIdx.y % H;
     const long ld = 3L * H * DH;
-    const float* qb = qkv + (long)b * n * ld + h * DH;
-    const float* kb = qb + (long)H * DH;
-    const float* vb = kb + (long)H * DH;
+    const QT* qb = qkv + (long)b * n * ld + h * DH;
+    const QT* kb = qb + (long)H * DH;
+    const QT* vb = kb + (long)H * DH;
     const int q0 = blockIdx.x * 128 + wave * 32;
     const bool active = q0 < n;
     const bool want_cls = cls_row != nullptr && blockIdx.x == 0 && wave == 0;
@@ -48,12 +61,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const float* __re
     bf16x8 qf[4];
     {
         const int qi = min(q0 + l31, n - 1);
-        const float* p = qb + (long)qi * ld + 8 * half;
+        const QT* p = qb + (long)qi * ld + 8 * half;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(p + 16 * kk), c = *reinterpret_cast<const f32x4*>(p + 16 * kk + 4);
+            f32x4 ac[2];
+            load8(p + 16 * kk, ac);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { qf[kk][j] = (__bf16)(a[j] * scale); qf[kk][4 + j] = (__bf16)(c[j] * scale); }
+            for (int j = 0; j < 4; ++j) { qf[kk][j] = (__bf16)(ac[0][j] * scale); qf[kk][4 + j] = (__bf16)(ac[1][j] * scale); }
         }
     }
 
@@ -68,10 +82,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const float* __re
     f32x4 kr[2], vr[2];
     auto fetch = [&](int t) {
         const long row = min(t * 32 + skey, n - 1);
-        const float* kp = kb + row * ld + sd8;
-        const float* vp = vb + row * ld + sd8;
-        kr[0] = *reinterpret_cast<const f32x4*>(kp); kr[1] = *reinterpret_cast<const f32x4*>(kp + 4);
-        vr[0] = *reinterpret_cast<const f32x4*>(vp); vr[1] = *reinterpret_cast<const f32x4*>(vp + 4);
+        load8(kb + row * ld + sd8, kr);
+        load8(vb + row * ld + sd8, vr);
     };
     fetch(0);
     for (int t = 0; t < ntiles; ++t) {
@@ -174,11 +186,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const float* __re
 }
 
 // staging helpers shared by the backward kernels: thread -> (row = tid / 8 of the 32-row tile, 8 consecutive d)
-__device__ __forceinline__ void stage_rows(const float* __restrict__ base, long ld, int row0, int n, int tid, f32x4 (&r)[2]) {
+template <typename T>
+__device__ __forceinline__ void stage_rows(const T* __restrict__ base, long ld, int row0, int n, int tid, f32x4 (&r)[2]) {
     const long row = min(row0 + (tid >> 3), n - 1);          // clamped: consumers mask by index / by lse = +inf
-    const float* p = base + row * ld + (tid & 7) * 8;
-    r[0] = *reinterpret_cast<const f32x4*>(p);
-    r[1] = *reinterpret_cast<const f32x4*>(p + 4);
+    load8(base + row * ld + (tid & 7) * 8, r);
 }
 __device__ __forceinline__ void put_rows(__bf16* __restrict__ S, int tid, const f32x4 (&r)[2], float scale) {      // [row][d], pitch KP
     bf16x8 v;
@@ -194,13 +205,15 @@ __device__ __forceinline__ void put_rows_t(__bf16* __restrict__ St, int tid, con
         St[(d8 + 4 + j) * VP + pos] = (__bf16)r[1][j];
     }
 }
-__device__ __forceinline__ void row_frags(const float* __restrict__ base, long ld, int row, int n, int half, float scale, bf16x8 (&f)[4]) {
-    const float* p = base + (long)min(row, n - 1) * ld + 8 * half;       // this lane's own row, d = 16 kk + 8 half + j
+template <typename T>
+__device__ __forceinline__ void row_frags(const T* __restrict__ base, long ld, int row, int n, int half, float scale, bf16x8 (&f)[4]) {
+    const T* p = base + (long)min(row, n - 1) * ld + 8 * half;       // this lane's own row, d = 16 kk + 8 half + j
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p + 16 * kk), c = *reinterpret_cast<const f32x4*>(p + 16 * kk + 4);
+        f32x4 ac[2];
+        load8(p + 16 * kk, ac);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { f[kk][j] = (__bf16)(a[j] * scale); f[kk][4 + j] = (__bf16)(c[j] * scale); }
+        for (int j = 0; j < 4; ++j) { f[kk][j] = (__bf16)(ac[0][j] * scale); f[kk][4 + j] = (__bf16)(ac[1][j] * scale); }
     }
 }
 __device__ __forceinline__ void pack2(const f32x16& s, bf16x8 (&pf)[2]) {
@@ -252,7 +265,8 @@ __device__ __forceinline__ void store_t(const f32x16 (&acc)[2], float* __restric
 }
 
 // ---- backward, dQ: a lane owns one query; loop over key tiles (S^T, dP^T, dS^T lane-local, dQ^T = K^T dS^T) ------------------------
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+template <typename QT>
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const QT* __restrict__ qkv, const float* __restrict__ dout,
                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
                                                                   float* __restrict__ dqkv, __bf16* __restrict__ dqkv16, int n, int H, float scale) {
     __shared__ __attribute__((aligned(16))) __bf16 Ks[32 * KP];
@@ -261,9 +275,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const float* _
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y / H, h = blockIdx.y % H;
     const long ld = 3L * H * DH, ldo = (long)H * DH;
-    const float* qb = qkv + (long)b * n * ld + h * DH;
-    const float* kb = qb + (long)H * DH;
-    const float* vb = kb + (long)H * DH;
+    const QT* qb = qkv + (long)b * n * ld + h * DH;
+    const QT* kb = qb + (long)H * DH;
+    const QT* vb = kb + (long)H * DH;
     const float* dob = dout + (long)b * n * ldo + h * DH;
     const int q0 = blockIdx.x * 128 + wave * 32;
     const bool active = q0 < n, qok = q0 + l31 < n;
@@ -305,7 +319,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const float* _
 }
 
 // ---- backward, dK / dV: a lane owns one key; loop over query tiles ------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+template <typename QT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const QT* __restrict__ qkv, const float* __restrict__ dout,
                                                                    const float* __restrict__ lse, const float* __restrict__ delta,
                                                                    float* __restrict__ dqkv, __bf16* __restrict__ dqkv16, int n, int H, float scale) {
     __shared__ __attribute__((aligned(16))) __bf16 Qs[32 * KP];
@@ -316,9 +331,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const float* 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y / H, h = blockIdx.y % H;
     const long ld = 3L * H * DH, ldo = (long)H * DH;
-    const float* qb = qkv + (long)b * n * ld + h * DH;
-    const float* kb = qb + (long)H * DH;
-    const float* vb = kb + (long)H * DH;
+    const QT* qb = qkv + (long)b * n * ld + h * DH;
+    const QT* kb = qb + (long)H * DH;
+    const QT* vb = kb + (long)H * DH;
     const float* dob = dout + (long)b * n * ldo + h * DH;
     const float* lse_b = lse + ((long)b * H + h) * n;
     const float* dl_b = delta + ((long)b * H + h) * n;
@@ -376,6 +391,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const float* 
 
 }  // namespace
 
+extern "C" int d2s_attn_delta(const float* out, const float* dout, float* delta, int B, int n, int H, hipStream_t stream);
+
+// Backward of the same mode (same contract as d2s_attn_bwd_f32): dqkv [B,n,3,H,64] fully written; delta_ws: [B,H,n] floats of scratch.
+template <typename QT>
+static int attn_bwd_bf16_impl(const QT* qkv, const float* out, const float* dout, const float* lse, float* dqkv, __bf16* dqkv16,
+                              float* delta_ws, int B, int n, int H, float scale, hipStream_t stream) {
+    if (!qkv || !out || !dout || !lse || !dqkv || !delta_ws || B <= 0 || n <= 0 || H <= 0) return D2S_ERR_ARG;
+    const int rc = d2s_attn_delta(out, dout, delta_ws, B, n, H, stream);
+    if (rc != D2S_OK) return rc;
+    dim3 grid((n + 127) / 128, B * H), block(256);
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<QT>, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, dqkv16, n, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<QT>, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, dqkv16, n, H, scale);
+    return d2s_check_launch();
+}
 extern "C" {
 
 // Same contract as d2s_attn_fwd_f32; Q, K, V rounded to bf16 for the two matrix products (bf16 arithmetic mode).
@@ -383,44 +412,40 @@ int d2s_attn_fwd_bf16(const float* qkv, float* out, float* lse, float* cls_row, 
                       hipStream_t stream) {
     if (!qkv || !out || !lse || B <= 0 || n <= 0 || H <= 0 || n > 8192) return D2S_ERR_ARG;
     dim3 grid((n + 127) / 128, B * H), block(256);
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, block, cls_row ? (size_t)n * sizeof(float) : 0, stream, qkv, out,
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel<float>, grid, block, cls_row ? (size_t)n * sizeof(float) : 0, stream, qkv, out,
                        static_cast<__bf16*>(nullptr), lse, cls_row, n, H, scale);
     return d2s_check_launch();
 }
 
-// The same forward with a dense [B, n, H*64] bf16 copy of the output (the a_bf16 of the projection GEMM); out may be NULL in forward-only
-// passes that consume the bf16 form alone.
-int d2s_attn_fwd_bf16_bf16out(const float* qkv, float* out, void* out_bf16, float* lse, float* cls_row, int B, int n, int H, float scale,
-                              hipStream_t stream) {
+// The same forward on the bf16 data path: qkv may be given in bf16 (qkv_is_bf16 != 0: the c_bf16 of the qkv GEMM, same [B,n,3,H,64]
+// layout - the values this kernel would round to itself, so the results are identical), and a dense [B, n, H*64] bf16 copy of the
+// output is written for the projection GEMM (its a_bf16); out may be NULL in forward-only passes that consume the bf16 form alone.
+int d2s_attn_fwd_bf16_bf16out(const void* qkv, int qkv_is_bf16, float* out, void* out_bf16, float* lse, float* cls_row, int B, int n, int H,
+                              float scale, hipStream_t stream) {
     if (!qkv || !out_bf16 || !lse || B <= 0 || n <= 0 || H <= 0 || n > 8192) return D2S_ERR_ARG;
     dim3 grid((n + 127) / 128, B * H), block(256);
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, block, cls_row ? (size_t)n * sizeof(float) : 0, stream, qkv, out,
-                       static_cast<__bf16*>(out_bf16), lse, cls_row, n, H, scale);
+    const size_t sh = cls_row ? (size_t)n * sizeof(float) : 0;
+    if (qkv_is_bf16)
+        hipLaunchKernelGGL(attn_fwd_bf16_kernel<__bf16>, grid, block, sh, stream, static_cast<const __bf16*>(qkv), out,
+                           static_cast<__bf16*>(out_bf16), lse, cls_row, n, H, scale);
+    else
+        hipLaunchKernelGGL(attn_fwd_bf16_kernel<float>, grid, block, sh, stream, static_cast<const float*>(qkv), out,
+                           static_cast<__bf16*>(out_bf16), lse, cls_row, n, H, scale);
     return d2s_check_launch();
 }
 
-int d2s_attn_delta(const float* out, const float* dout, float* delta, int B, int n, int H, hipStream_t stream);
-
-// Backward of the same mode (same contract as d2s_attn_bwd_f32): dqkv [B,n,3,H,64] fully written; delta_ws: [B,H,n] floats of scratch.
-static int attn_bwd_bf16_impl(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, __bf16* dqkv16,
-                              float* delta_ws, int B, int n, int H, float scale, hipStream_t stream) {
-    if (!qkv || !out || !dout || !lse || !dqkv || !delta_ws || B <= 0 || n <= 0 || H <= 0) return D2S_ERR_ARG;
-    const int rc = d2s_attn_delta(out, dout, delta_ws, B, n, H, stream);
-    if (rc != D2S_OK) return rc;
-    dim3 grid((n + 127) / 128, B * H), block(256);
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, dqkv16, n, H, scale);
-    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, block, 0, stream, qkv, dout, lse, delta_ws, dqkv, dqkv16, n, H, scale);
-    return d2s_check_launch();
-}
 int d2s_attn_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws, int B, int n,
                       int H, float scale, hipStream_t stream) {
-    return attn_bwd_bf16_impl(qkv, out, dout, lse, dqkv, nullptr, delta_ws, B, n, H, scale, stream);
+    return attn_bwd_bf16_impl<float>(qkv, out, dout, lse, dqkv, nullptr, delta_ws, B, n, H, scale, stream);
 }
-// ... with a bf16 copy of dqkv (same [B,n,3,H,64] layout): the a_bf16 of the qkv Linear's input-gradient GEMM
-int d2s_attn_bwd_bf16_bf16out(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, void* dqkv_bf16,
-                              float* delta_ws, int B, int n, int H, float scale, hipStream_t stream) {
+// ... on the bf16 data path: qkv optionally in bf16 (as in the forward), and a bf16 copy of dqkv (same [B,n,3,H,64] layout): the a_bf16
+// of the qkv Linear's input-gradient GEMM
+int d2s_attn_bwd_bf16_bf16out(const void* qkv, int qkv_is_bf16, const float* out, const float* dout, const float* lse, float* dqkv,
+                              void* dqkv_bf16, float* delta_ws, int B, int n, int H, float scale, hipStream_t stream) {
     if (!dqkv_bf16) return D2S_ERR_ARG;
-    return attn_bwd_bf16_impl(qkv, out, dout, lse, dqkv, static_cast<__bf16*>(dqkv_bf16), delta_ws, B, n, H, scale, stream);
+    if (qkv_is_bf16)
+        return attn_bwd_bf16_impl<__bf16>(static_cast<const __bf16*>(qkv), out, dout, lse, dqkv, static_cast<__bf16*>(dqkv_bf16), delta_ws, B, n, H, scale, stream);
+    return attn_bwd_bf16_impl<float>(static_cast<const float*>(qkv), out, dout, lse, dqkv, static_cast<__bf16*>(dqkv_bf16), delta_ws, B, n, H, scale, stream);
 }
 
 }  // extern "C"

@@ -151,7 +151,11 @@ class BlockFn(torch.autograd.Function):
             # block at B=128), nothing saved; on the bf16 data path not even the fp32 form of the GEMM inputs
             if io:
                 _, _, _, ln1h = ops.layernorm_fwd_bf16(x, cmap, n1w, n1b, M, D, eps, stats=False, want_f32=False)
-                qkv = ops.linear_fwd(None, qkvw, qkvb, a16=ln1h)
+                if io_attn:      # the bf16 attention kernel rounds q, k, v to bf16 anyway: the qkv GEMM writes only that form
+                    qkv = ops.bf16_buffer(M, 3 * D, x.device)
+                    ops.linear_fwd(None, qkvw, qkvb, a16=ln1h, c16=qkv, want_f32=False)
+                else:
+                    qkv = ops.linear_fwd(None, qkvw, qkvb, a16=ln1h)
                 del ln1h
                 if io_attn:
                     ao, _, cls_row, aoh = ops.attn_fwd_bf16io(qkv, B, n, heads, scale, want_cls, want_f32=False)
@@ -190,7 +194,11 @@ class BlockFn(torch.autograd.Function):
             ln1, mean1, rstd1, ln1h = ops.layernorm_fwd_bf16(x, cmap, n1w, n1b, M, D, eps)
         else:
             ln1, mean1, rstd1 = ops.layernorm_fwd(x, cmap, n1w, n1b, M, D, eps)
-        qkv = ops.linear_fwd(ln1, qkvw, qkvb, a16=ln1h)
+        if io_attn:          # bf16 qkv only (see the forward-only branch); saved for the backward in that form
+            qkv = ops.bf16_buffer(M, 3 * D, x.device)
+            ops.linear_fwd(None, qkvw, qkvb, a16=ln1h, c16=qkv, want_f32=False)
+        else:
+            qkv = ops.linear_fwd(ln1, qkvw, qkvb, a16=ln1h)
         del ln1h
         cinv = None
         if io_attn:

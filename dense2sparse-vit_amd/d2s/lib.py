@@ -52,10 +52,10 @@ _SIGS = {
     "d2s_performer_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, F, P, Z]),
     "d2s_attn_fwd_f32": (I, [P, P, P, P, I, I, I, F]),
     "d2s_attn_fwd_bf16": (I, [P, P, P, P, I, I, I, F]),
-    "d2s_attn_fwd_bf16_bf16out": (I, [P, P, P, P, P, I, I, I, F]),
+    "d2s_attn_fwd_bf16_bf16out": (I, [P, I, P, P, P, P, I, I, I, F]),
     "d2s_attn_bwd_f32": (I, [P, P, P, P, P, P, I, I, I, F]),
     "d2s_attn_bwd_bf16": (I, [P, P, P, P, P, P, I, I, I, F]),
-    "d2s_attn_bwd_bf16_bf16out": (I, [P, P, P, P, P, P, P, I, I, I, F]),
+    "d2s_attn_bwd_bf16_bf16out": (I, [P, I, P, P, P, P, P, P, I, I, I, F]),
     "d2s_attn_delta": (I, [P, P, P, I, I, I]),
     "d2s_attn_bwd_dq_f32": (I, [P, P, P, P, P, I, I, I, F]),
     "d2s_attn_bwd_dkv_f32": (I, [P, P, P, P, P, I, I, I, F]),

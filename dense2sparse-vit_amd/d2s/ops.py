@@ -479,25 +479,29 @@ def attn_fwd(qkv, B, n, H, scale, want_cls=True):
 
 
 def attn_fwd_bf16io(qkv, B, n, H, scale, want_cls=True, want_f32=True):
-    """bf16-mode attention forward that also (or only) writes the bf16 copy of its output.  -> (out or None, lse, cls_row, out16)"""
+    """bf16-mode attention forward that also (or only) writes the bf16 copy of its output; qkv fp32 or bf16 (the qkv GEMM's c16).
+    -> (out or None, lse, cls_row, out16)"""
+    assert qkv.is_contiguous() and qkv.dtype in (torch.float32, torch.bfloat16)
     out = torch.empty((B * n, H * 64), dtype=torch.float32, device=qkv.device) if want_f32 else None
     out16 = bf16_buffer(B * n, H * 64, qkv.device)
     lse = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device)
     cls_row = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device) if want_cls else None
-    lib.call("d2s_attn_fwd_bf16_bf16out", lib.ptr(qkv), lib.ptr(out), lib.ptr(out16), lib.ptr(lse), lib.ptr(cls_row), B, n, H, float(scale))
+    lib.call("d2s_attn_fwd_bf16_bf16out", lib.ptr(qkv), int(qkv.dtype == torch.bfloat16), lib.ptr(out), lib.ptr(out16), lib.ptr(lse),
+             lib.ptr(cls_row), B, n, H, float(scale))
     return out, lse, cls_row, out16
 
 
 def attn_bwd(qkv, out, dout, lse, B, n, H, scale, dqkv16=None):
     """dqkv16 (bf16 mode with the bf16 attention kernels): bf16 buffer shaped like qkv that receives a copy of dqkv."""
-    dqkv = torch.empty_like(qkv)
+    dqkv = torch.empty(qkv.shape, dtype=torch.float32, device=qkv.device)
     delta = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device)
     bf16 = get_gemm_mode() == GEMM_BF16 and _BF16_ATTENTION
     if dqkv16 is not None:
         assert bf16 and dqkv16.dtype == torch.bfloat16 and dqkv16.is_contiguous() and dqkv16.numel() == qkv.numel()
-        lib.call("d2s_attn_bwd_bf16_bf16out", lib.ptr(qkv), lib.ptr(out), lib.ptr(dout), lib.ptr(lse), lib.ptr(dqkv), lib.ptr(dqkv16),
-                 lib.ptr(delta), B, n, H, float(scale))
+        lib.call("d2s_attn_bwd_bf16_bf16out", lib.ptr(qkv), int(qkv.dtype == torch.bfloat16), lib.ptr(out), lib.ptr(dout), lib.ptr(lse),
+                 lib.ptr(dqkv), lib.ptr(dqkv16), lib.ptr(delta), B, n, H, float(scale))
         return dqkv
+    assert qkv.dtype == torch.float32
     if _WGRAD["on"] and _ATTN_BWD_STREAMS and not bf16 and qkv.is_cuda:
         # inside TrainStep's backward: the dK/dV kernel on a stream of its own beside the dQ kernel (independent, disjoint outputs);
         # both are joined again before anything reads dqkv

@@ -103,9 +103,11 @@ int d2s_attn_fwd_f32(const float* qkv, float* out, float* lse, float* cls_row, i
  * arithmetic mode.  The fp32 backward below works from its outputs unchanged. */
 int d2s_attn_fwd_bf16(const float* qkv, float* out, float* lse, float* cls_row, int B, int n, int H, float scale,
                       d2s_stream_t stream);
-/* ... with a dense [B, n, H*64] bf16 copy of the output for the projection GEMM (out may be NULL in forward-only passes) */
-int d2s_attn_fwd_bf16_bf16out(const float* qkv, float* out, void* out_bf16, float* lse, float* cls_row, int B, int n, int H, float scale,
-                              d2s_stream_t stream);
+/* ... on the bf16 data path: qkv may be given in bf16 (qkv_is_bf16 != 0: the c_bf16 of the qkv GEMM, same layout - the values the
+ * kernel rounds to itself, so results are identical), and a dense [B, n, H*64] bf16 copy of the output is written for the projection
+ * GEMM (out may be NULL in forward-only passes) */
+int d2s_attn_fwd_bf16_bf16out(const void* qkv, int qkv_is_bf16, float* out, void* out_bf16, float* lse, float* cls_row, int B, int n, int H,
+                              float scale, d2s_stream_t stream);
 int d2s_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws,
                      int B, int n, int H, float scale, d2s_stream_t stream);
 /* the two independent halves of d2s_attn_bwd_f32 (delta_ws [B,H,n] from d2s_attn_delta): dQ, and dK / dV; they write disjoint parts of
@@ -119,9 +121,10 @@ int d2s_attn_delta(const float* out, const float* dout, float* delta, int B, int
 /* backward on the bf16 matrix cores (bf16 arithmetic mode), same contract as d2s_attn_bwd_f32 */
 int d2s_attn_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws,
                      int B, int n, int H, float scale, d2s_stream_t stream);
-/* ... with a bf16 copy of dqkv in the same [B,n,3,H,64] layout (the a_bf16 of the qkv Linear's input-gradient GEMM) */
-int d2s_attn_bwd_bf16_bf16out(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, void* dqkv_bf16,
-                              float* delta_ws, int B, int n, int H, float scale, d2s_stream_t stream);
+/* ... on the bf16 data path: qkv optionally in bf16 (as in the forward) and a bf16 copy of dqkv in the same [B,n,3,H,64] layout (the
+ * a_bf16 of the qkv Linear's input-gradient GEMM) */
+int d2s_attn_bwd_bf16_bf16out(const void* qkv, int qkv_is_bf16, const float* out, const float* dout, const float* lse, float* dqkv,
+                              void* dqkv_bf16, float* delta_ws, int B, int n, int H, float scale, d2s_stream_t stream);
 
 /* Attention.softmax_with_policy (vit_models/dynamic_vit.py:195-214) on materialised scores [B,H,N,N], policy [B,N];
  * the backward includes the path through the row maximum (the reference does not detach it). */

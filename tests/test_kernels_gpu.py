@@ -388,6 +388,34 @@ def test_gemm_bf16_io(ops, M, N, K):
         ops.set_gemm_mode(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 1536, 768), (36928, 768, 768), (8192, 384, 768), (5000, 768, 3072)])      # 256x256, 256x256, 256x128, 256x128 tiles
+def test_gemm_bf16_dma_race_screen(ops, M, N, K):
+    """The LDS-DMA kernel orders its LDS traffic by hand (counted vmcnt waits + raw barriers, persistent workgroups).  The summation
+    order is fixed, so repeated launches must be bit-identical; a read that runs ahead of its DMA, or a DMA that overwrites a buffer still
+    being read, shows up as a launch that differs.  40 launches per shape (the first checked against a float64 product of the rounded
+    operands), on both tile shapes and with other work keeping the memory system busy in between."""
+    ops.set_gemm_mode(2)
+    try:
+        g = torch.Generator().manual_seed(M + N + K)
+        x = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) * 0.05
+        b = torch.randn(N, generator=g)
+        xd, wd, bd = x.to(_dev()), w.to(_dev()), b.to(_dev())
+        x16 = xd.bfloat16()
+        noise = torch.empty(64 << 20, device=_dev())
+        first = ops.linear_fwd(xd, wd, bd, a16=x16).clone()
+        rows = torch.randint(0, M, (256,), generator=g)
+        ref = (x[rows].bfloat16().double() @ w.bfloat16().double().t() + b.double()).float()
+        np.testing.assert_allclose(first[rows.to(_dev())].cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+        for i in range(40):
+            if i % 3 == 0:
+                noise.normal_()                 # evict / load the memory system between launches
+            out = ops.linear_fwd(xd, wd, bd, a16=x16)
+            assert torch.equal(out, first), f"launch {i} differs from the first: max |diff| {float((out - first).abs().max()):.3e}"
+    finally:
+        ops.set_gemm_mode(0)
+
+
 def test_bf16_io_rejected_outside_bf16_mode(ops):
     """The bf16 side channels exist in mode 2 only: every other use is an argument error, not a silent fp32 path."""
     from d2s import lib
@@ -447,6 +475,9 @@ def test_attn_bwd_bf16out(ops):
         d16 = torch.empty(qkv.shape, dtype=torch.bfloat16, device=_dev())
         d2 = ops.attn_bwd(qkv, out, dout, lse, B, n, H, 0.125, dqkv16=d16)
         assert torch.equal(d1, d2) and torch.equal(d16, d1.bfloat16())
+        d16b = torch.empty_like(d16)
+        d3 = ops.attn_bwd(qkv.bfloat16(), out, dout, lse, B, n, H, 0.125, dqkv16=d16b)      # bf16 qkv in: identical gradients
+        assert torch.equal(d3, d1) and torch.equal(d16b, d16)
     finally:
         ops.set_gemm_mode(0)
 
@@ -463,6 +494,10 @@ def test_attn_fwd_bf16out(ops):
         assert torch.equal(o16, out.bfloat16())
         out3, _, _, o16b = ops.attn_fwd_bf16io(qkv, B, n, H, 0.125, False, want_f32=False)
         assert out3 is None and torch.equal(o16b, o16)
+        # qkv handed over in bf16 (the qkv GEMM's bf16 copy): the kernel rounds to the same numbers itself -> identical results
+        q16 = qkv.bfloat16()
+        out4, lse4, cls4, o16c = ops.attn_fwd_bf16io(q16, B, n, H, 0.125, True)
+        assert torch.equal(out4, out) and torch.equal(lse4, lse) and torch.equal(cls4, cls_row) and torch.equal(o16c, o16)
     finally:
         ops.set_gemm_mode(0)
 
