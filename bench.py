@@ -155,8 +155,9 @@ class KernelTimer:
             s.record()
             out = orig_wgrad(dy, x, dW, *a, **kw)
             e.record()
-            timer.records.setdefault(("gemm_f32", "TN"), []).append((s, e, 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1]))
-            timer.shapes.setdefault(("TN", dy.shape[1], x.shape[1], dy.shape[0]), []).append((s, e))
+            xin = x if x is not None else kw["x16"]          # bf16 data path: the layer input was saved in bf16 only
+            timer.records.setdefault(("gemm_f32", "TN"), []).append((s, e, 2.0 * dy.shape[0] * dy.shape[1] * xin.shape[1]))
+            timer.shapes.setdefault(("TN", dy.shape[1], xin.shape[1], dy.shape[0]), []).append((s, e))
             return out
 
         ops.linear_wgrad = linear_wgrad

@@ -927,9 +927,14 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
                      int K, int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, int aux_rows,
                      int remap_rows_per_img, int remap_skip, int accumulate, void* workspace, size_t workspace_bytes,
                      hipStream_t stream, float* colsum_out, int mode, const void* a16 = nullptr, void* c16 = nullptr) {
-    if ((!A && !a16) || !B || (!C && !c16) || M <= 0 || N <= 0 || K <= 0 || layout < 0 || layout > 2 || mode < 0 || mode > 2) return D2S_ERR_ARG;
-    if ((a16 || c16) && (mode != 2 || layout == 2 || accumulate || remap_rows_per_img > 0)) return D2S_ERR_ARG;   // bf16 operands / copies exist in bf16 mode only
-    if ((a16 && (K % 32 != 0 || !aligned16(a16))) || (c16 && (N % 32 != 0 || !aligned16(c16)))) return D2S_ERR_ARG;
+    // layout 2 (weight gradient): a16 is the bf16 form of the SECOND operand (the layer input x); B may then be NULL
+    if ((!A && !(a16 && layout != 2)) || (!B && !(a16 && layout == 2)) || (!C && !c16) || M <= 0 || N <= 0 || K <= 0 || layout < 0 || layout > 2 || mode < 0 || mode > 2) return D2S_ERR_ARG;
+    if ((a16 || c16) && (mode != 2 || (layout != 2 && accumulate) || remap_rows_per_img > 0)) return D2S_ERR_ARG;   // bf16 operands / copies exist in bf16 mode only
+    if (layout == 2 && (c16 || (a16 && !bf16_wgrad(mode)))) return D2S_ERR_ARG;
+    if (layout == 2 && a16) {
+        if ((reinterpret_cast<uintptr_t>(a16) & 7) != 0) return D2S_ERR_ARG;
+    }
+    if ((a16 && layout != 2 && (K % 32 != 0 || !aligned16(a16))) || (c16 && (N % 32 != 0 || !aligned16(c16)))) return D2S_ERR_ARG;
     if ((epilogue == EPI_BIAS_RESID || epilogue == EPI_MUL_GELU_GRAD || epilogue == EPI_MUL_RELU_MASK ||
          epilogue == EPI_BIAS_ROWADD) && !aux)
         return D2S_ERR_ARG;
@@ -1060,6 +1065,7 @@ int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb,
 int d2s_gemm_f32_bf16io(int layout, const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
                         int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, const void* a_bf16, void* c_bf16,
                         void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (layout == 2) return D2S_ERR_ARG;      // weight gradients with a bf16 input: d2s_linear_wgrad_f32_bf16x
     return gemm_impl(layout, A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, aux, ldaux, aux_out, 0, 0, 0, 0, workspace, workspace_bytes,
                      stream, nullptr, 2, a_bf16, c_bf16);
 }
@@ -1073,6 +1079,14 @@ int d2s_linear_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, f
                          int n_out, int n_in, int accumulate, int mode, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     return gemm_impl(2, dy, lddy, x, ldx, dW, lddw, n_out, n_in, tokens, EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0,
                      accumulate, workspace, workspace_bytes, stream, db, mode);
+}
+// The same in mode 2 with the layer input given in bf16 only (x_bf16 [tokens][n_in], row stride ldx elements): what the bf16 data path
+// saved for the backward instead of the fp32 activation.  dy stays fp32 (its exact column sums are the bias gradient).
+int d2s_linear_wgrad_f32_bf16x(const float* dy, long lddy, const void* x_bf16, long ldx, float* dW, long lddw, float* db, int tokens,
+                               int n_out, int n_in, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!x_bf16) return D2S_ERR_ARG;
+    return gemm_impl(2, dy, lddy, nullptr, ldx, dW, lddw, n_out, n_in, tokens, EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0,
+                     accumulate, workspace, workspace_bytes, stream, db, 2, x_bf16, nullptr);
 }
 
 // dst[C][R] = src[R][C]^T (dense row-major): the k-contiguous copy of a Linear weight for the input-gradient GEMM.

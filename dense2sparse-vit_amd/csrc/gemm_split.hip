@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 // ---- stage 1b: source [K][R] (ld, row index contiguous) -> pieces [SPLIT][R][Kp]: 64 x 64 transposes through LDS ----------------
 // Loads: 16 bytes along r (4 rows of one k).  Stores: 16 bytes along k (8 bf16 of one row); a wave covers 8 rows x 128 contiguous
 // bytes per instruction.  LDS image [64 k][65]: the column walk of the store phase is at worst 2-way conflicted.
-template <int SPLIT>
-__global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict__ src, long ld, __bf16* __restrict__ dst, int R, int K,
+template <int SPLIT, typename ST = float>
+__global__ __launch_bounds__(256) void split_cols_kernel(const ST* __restrict__ src, long ld, __bf16* __restrict__ dst, int R, int K,
                                                          int Kp, int vec, float* __restrict__ colsum_part) {
     __shared__ float t[64][65];
     __shared__ float csum[4][64];
@@ -83,13 +83,19 @@ __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict
         const int f = tid + i * 256, k = f >> 4, r4 = (f & 15) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (k0 + k < K) {
-            const float* p = src + (long)(k0 + k) * ld + r0 + r4;
+            const ST* p = src + (long)(k0 + k) * ld + r0 + r4;
             if (vec && r0 + r4 + 3 < R) {
-                v = *reinterpret_cast<const f32x4*>(p);
+                if constexpr (sizeof(ST) == 4) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {      // bf16 source (the bf16 data path's saved activations): 8-byte loads
+                    const bf16x4 h4 = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (float)h4[j];
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (r0 + r4 + j < R) v[j] = p[j];
+                    if (r0 + r4 + j < R) v[j] = (float)p[j];
             }
         }
 #pragma unroll
@@ -681,7 +687,11 @@ int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_
     __bf16* Bp = reinterpret_cast<__bf16*>(static_cast<unsigned char*>(pieces_ws) + align256((size_t)split * p.M * Kp * sizeof(__bf16)));
     dim3 block(256);
     hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.M + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA, colsum_part);
-    hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB, static_cast<float*>(nullptr));
+    if (p.a16)      // weight gradient on the bf16 data path: the layer input x ([tokens][n_in]) was saved in bf16 only
+        hipLaunchKernelGGL((split_cols_kernel<1, __bf16>), dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, static_cast<const __bf16*>(p.a16), p.ldb, Bp,
+                           p.N, p.K, Kp, (int)((p.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.a16) & 7) == 0)), static_cast<float*>(nullptr));
+    else
+        hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB, static_cast<float*>(nullptr));
     GemmArgs pv = p;                      // p.C / p.ldc / p.slab_stride / p.k_per_slice / p.epi were set by the caller
     pv.vec_epilogue = (epilogue_vec_ok(p) && (p.slab_stride % 4 == 0)) ? 1 : 0;
     pv.a16 = nullptr; pv.c16 = nullptr;

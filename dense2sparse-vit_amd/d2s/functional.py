@@ -190,15 +190,18 @@ class BlockFn(torch.autograd.Function):
                 cls_row = torch.empty((0,), device=x.device)
             return y.view(B, n, D), cls_row
         ln1h = aoh = ln2h = hh = None
-        if io:
-            ln1, mean1, rstd1, ln1h = ops.layernorm_fwd_bf16(x, cmap, n1w, n1b, M, D, eps)
+        if io:      # the GEMMs read the bf16 forms and so do the weight gradients: LayerNorm outputs and the GELU activation are kept in bf16 only
+            _, mean1, rstd1, ln1h = ops.layernorm_fwd_bf16(x, cmap, n1w, n1b, M, D, eps, want_f32=False)
+            ln1 = ln1h
         else:
             ln1, mean1, rstd1 = ops.layernorm_fwd(x, cmap, n1w, n1b, M, D, eps)
         if io_attn:          # bf16 qkv only (see the forward-only branch); saved for the backward in that form
             qkv = ops.bf16_buffer(M, 3 * D, x.device)
             ops.linear_fwd(None, qkvw, qkvb, a16=ln1h, c16=qkv, want_f32=False)
+        elif io:
+            qkv = ops.linear_fwd(None, qkvw, qkvb, a16=ln1h)
         else:
-            qkv = ops.linear_fwd(ln1, qkvw, qkvb, a16=ln1h)
+            qkv = ops.linear_fwd(ln1, qkvw, qkvb)
         del ln1h
         cinv = None
         if io_attn:
@@ -210,16 +213,19 @@ class BlockFn(torch.autograd.Function):
         x2d = x.view(M, D)
         x1 = ops.linear_fwd(ao, projw, projb, epi=ops.EPI_BIAS_RESID, aux=x2d, a16=aoh)
         del aoh
+        z = torch.empty((M, hidden), dtype=torch.float32, device=x.device)
         if io:
-            ln2, mean2, rstd2, ln2h = ops.layernorm_fwd_bf16(x1, cmap, n2w, n2b, M, D, eps)
+            _, mean2, rstd2, ln2h = ops.layernorm_fwd_bf16(x1, cmap, n2w, n2b, M, D, eps, want_f32=False)
+            ln2 = ln2h
             hh = ops.bf16_buffer(M, hidden, x.device)
+            ops.linear_fwd(None, fc1w, fc1b, epi=ops.EPI_BIAS_GELU, aux_out=z, a16=ln2h, c16=hh, want_f32=False)
+            h = hh
+            y = ops.linear_fwd(None, fc2w, fc2b, epi=ops.EPI_BIAS_RESID, aux=x1, a16=hh)
         else:
             ln2, mean2, rstd2 = ops.layernorm_fwd(x1, cmap, n2w, n2b, M, D, eps)
-        z = torch.empty((M, hidden), dtype=torch.float32, device=x.device)
-        h = ops.linear_fwd(ln2, fc1w, fc1b, epi=ops.EPI_BIAS_GELU, aux_out=z, a16=ln2h, c16=hh)
-        del ln2h
-        y = ops.linear_fwd(h, fc2w, fc2b, epi=ops.EPI_BIAS_RESID, aux=x1, a16=hh)
-        del hh
+            h = ops.linear_fwd(ln2, fc1w, fc1b, epi=ops.EPI_BIAS_GELU, aux_out=z)
+            y = ops.linear_fwd(h, fc2w, fc2b, epi=ops.EPI_BIAS_RESID, aux=x1)
+        del ln2h, hh
         ctx.save_for_backward(x, n1w, qkvw, projw, n2w, fc1w, fc2w, mean1, rstd1, ln1, qkv, ao, lse, x1, mean2, rstd2, ln2, z, h,
                               n1b, qkvb, projb, n2b, fc1b, fc2b)
         ctx.policy = (policy, cinv)
@@ -245,7 +251,10 @@ class BlockFn(torch.autograd.Function):
         new = ops.grad_buffer
 
         # ---- MLP branch ----
-        grads[11], grads[12] = ops.linear_param_grads(gy, h, fc2w, fc2b, wants[11], wants[12])
+        def xarg(t):      # a saved layer input is fp32, or bf16 only on the bf16 data path
+            return (None, t) if t.dtype == torch.bfloat16 else (t, None)
+        hx, h16 = xarg(h)
+        grads[11], grads[12] = ops.linear_param_grads(gy, hx, fc2w, fc2b, wants[11], wants[12], x16=h16)
         # bf16 data path: every gradient that feeds an input-gradient GEMM is also produced in bf16 by the kernel that computes it
         io = ops.bf16_io() and z.shape[1] % 32 == 0 and D % 32 == 0 and gy.is_cuda
         policy, cinv = ctx.policy
@@ -256,7 +265,8 @@ class BlockFn(torch.autograd.Function):
         dzh = ops.bf16_buffer(M, z.shape[1], dev) if io else None
         dz = ops.linear_dgrad(gy, fc2w, epi=ops.EPI_MUL_GELU_GRAD, aux=z, a16=gyh, c16=dzh)
         del gyh
-        grads[9], grads[10] = ops.linear_param_grads(dz, ln2, fc1w, fc1b, wants[9], wants[10])
+        l2x, l216 = xarg(ln2)
+        grads[9], grads[10] = ops.linear_param_grads(dz, l2x, fc1w, fc1b, wants[9], wants[10], x16=l216)
         dln2 = ops.linear_dgrad(dz, fc1w, a16=dzh)
         del dzh
         g1 = torch.empty((M, D), dtype=torch.float32, device=dev)
@@ -276,7 +286,8 @@ class BlockFn(torch.autograd.Function):
             dqkv = ops.attn_bwd(qkv, ao, dao, lse, B, n, heads, scale, dqkv16=dqkvh)
         else:
             dqkv = ops.attn_policy_bwd(qkv, policy, ao, dao, lse, cinv, B, n, heads, scale)
-        grads[3], grads[4] = ops.linear_param_grads(dqkv, ln1, qkvw, qkvb, wants[3], wants[4])
+        l1x, l116 = xarg(ln1)
+        grads[3], grads[4] = ops.linear_param_grads(dqkv, l1x, qkvw, qkvb, wants[3], wants[4], x16=l116)
         gx = None
         if wants[0] or wants[1] or wants[2]:
             dln1 = ops.linear_dgrad(dqkv, qkvw, a16=dqkvh)

@@ -206,14 +206,21 @@ def linear_dgrad(dy, W, epi=EPI_NONE, aux=None, out=None, a16=None, c16=None):
     return gemm(NN, dy, N, W, K, out, K, M, K, N, epi, None, aux, K if aux is not None else 0)
 
 
-def linear_wgrad(dy, x, dW, accumulate=False, db=None):
-    """dW[N,K] (+)= dy[M,N]^T @ x[M,K]; with db also db[N] (+)= dy.sum(0), folded into the same pass over dy."""
-    _f32(dy), _f32(x), _f32(dW)
+def linear_wgrad(dy, x, dW, accumulate=False, db=None, x16=None):
+    """dW[N,K] (+)= dy[M,N]^T @ x[M,K]; with db also db[N] (+)= dy.sum(0), folded into the same pass over dy.
+    bf16 mode: x16 = the layer input in bf16 (x may then be None - the bf16 data path saves only that form)."""
+    _f32(dy), _f32(dW)
     M, N = dy.shape
-    K = x.shape[1]
+    K = (x if x is not None else x16).shape[1]
     mode = get_gemm_mode()
     need = lib.query("d2s_linear_wgrad_workspace_bytes", M, N, K, mode)
     ws = workspace(need, dW.device) if need else None
+    if x16 is not None:
+        assert mode == GEMM_BF16 and x16.dtype == torch.bfloat16 and x16.is_contiguous() and tuple(x16.shape) == (M, K)
+        lib.call("d2s_linear_wgrad_f32_bf16x", lib.ptr(dy), N, lib.ptr(x16), K, lib.ptr(dW), K, lib.ptr(db), M, N, K, int(accumulate),
+                 lib.ptr(ws), ws.numel() if ws is not None else 0)
+        return dW
+    _f32(x)
     lib.call("d2s_linear_wgrad_f32", lib.ptr(dy), N, lib.ptr(x), K, lib.ptr(dW), K, lib.ptr(db), M, N, K, int(accumulate), mode,
              lib.ptr(ws), ws.numel() if ws is not None else 0)
     return dW
@@ -258,8 +265,8 @@ def join_weight_grads():
     _WGRAD["used"] = False
 
 
-def linear_param_grads(dy, x, W, b, want_w=True, want_b=True, accumulate=False):
-    """(dW, db) of a Linear into fresh arena-backed buffers: one fused pass when both are wanted."""
+def linear_param_grads(dy, x, W, b, want_w=True, want_b=True, accumulate=False, x16=None):
+    """(dW, db) of a Linear into fresh arena-backed buffers: one fused pass when both are wanted.  x16: see linear_wgrad."""
     dW = grad_buffer(W) if want_w else None
     db = grad_buffer(b) if (want_b and b is not None) else None
     if dW is None and db is None:
@@ -267,7 +274,7 @@ def linear_param_grads(dy, x, W, b, want_w=True, want_b=True, accumulate=False):
     side = _WGRAD["stream"] if (_WGRAD["on"] and dy.is_cuda) else None
     if side is None:
         if dW is not None:
-            linear_wgrad(dy, x, dW, accumulate=accumulate, db=db)
+            linear_wgrad(dy, x, dW, accumulate=accumulate, db=db, x16=x16)
         else:
             colsum(dy, db, accumulate=accumulate)
         return dW, db
@@ -275,10 +282,10 @@ def linear_param_grads(dy, x, W, b, want_w=True, want_b=True, accumulate=False):
     side.wait_stream(main)                       # dy (and x) were produced on the main stream
     with torch.cuda.stream(side):
         if dW is not None:
-            linear_wgrad(dy, x, dW, accumulate=accumulate, db=db)
+            linear_wgrad(dy, x, dW, accumulate=accumulate, db=db, x16=x16)
         else:
             colsum(dy, db, accumulate=accumulate)
-    for t in (dy, x, dW, db):                    # autograd may free these on the main stream while the side stream still reads / writes them
+    for t in (dy, x, x16, dW, db):                    # autograd may free these on the main stream while the side stream still reads / writes them
         if t is not None:
             t.record_stream(side)
     _WGRAD["used"] = True

@@ -529,6 +529,24 @@ def test_linear_wgrad_bf16_mode(ops, tokens, n_out, n_in):
         ops.set_gemm_mode(ops.GEMM_EXACT)
 
 
+@pytest.mark.parametrize("tokens,n_out,n_in", [(197 * 8, 384, 1536), (5000, 768, 768), (1001, 96, 200)])
+def test_linear_wgrad_bf16_input(ops, tokens, n_out, n_in):
+    """d2s_linear_wgrad_f32_bf16x: with the layer input handed over in bf16 (what the bf16 data path saves) the weight and bias gradients
+    are bit-identical to the fp32-input call, which rounds the same values itself."""
+    g = torch.Generator().manual_seed(tokens)
+    dy = torch.randn(tokens, n_out, generator=g).to(_dev())
+    x = torch.randn(tokens, n_in, generator=g).to(_dev())
+    ops.set_gemm_mode(ops.GEMM_BF16)
+    try:
+        dW1, db1 = torch.empty(n_out, n_in, device=_dev()), torch.empty(n_out, device=_dev())
+        ops.linear_wgrad(dy, x, dW1, db=db1)
+        dW2, db2 = torch.empty(n_out, n_in, device=_dev()), torch.empty(n_out, device=_dev())
+        ops.linear_wgrad(dy, None, dW2, db=db2, x16=x.bfloat16())
+        assert torch.equal(dW1, dW2) and torch.equal(db1, db2)
+    finally:
+        ops.set_gemm_mode(ops.GEMM_EXACT)
+
+
 @pytest.mark.parametrize("M,N,K", [(600, 384, 1536), (3168, 384, 1536), (257, 96, 2048), (1000, 200, 1024)])
 def test_gemm_small_grid_split_k_epilogues(ops, M, N, K):
     """Forward / dgrad GEMMs with a small tile grid and a long K split K and apply their epilogue in the ordered slab combine
