@@ -260,13 +260,14 @@ def cpu_baseline(keep, batch=32, warm=2, steps=10):
 
 
 PMC_FILE = "r02_g_pmc_traffic.json"
+PMC_FILE_C5 = "r02_g_pmc_traffic_c5.json"      # the same two passes over `bench.py --config c5`
 
 
-def pmc_traffic(kernel_prefix):
+def pmc_traffic(kernel_prefix, pmc_file=None):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, KB -> bytes): the launch-weighted
     mean over every kernel whose name starts with `kernel_prefix` (the tile-shape variants of one GEMM layout), or None."""
     try:
-        with open(os.path.join(REPO, "profiles", PMC_FILE)) as f:
+        with open(os.path.join(REPO, "profiles", pmc_file or PMC_FILE)) as f:
             ks = json.load(f)["kernels"]
         sel = [v for k, v in ks.items() if k.startswith(kernel_prefix)]
         n = sum(v["launches"] for v in sel)
@@ -460,8 +461,8 @@ def main():
                 kern = "gemm_f32_rk_kernel"
             line["roofline"] = {"bound": "mfma", "kernel": f"{kern}, {dom[1]} layout ({instr})",
                                 "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                                "frac": round(ach / peak, 4), "traffic": pmc_traffic(pmc_prefix),
-                                "traffic_note": f"HBM bytes per launch, launch-weighted mean over this layout's tile-shape variants, from the committed PMC passes (profiles/{PMC_FILE}); not collected live",
+                                "frac": round(ach / peak, 4), "traffic": pmc_traffic(pmc_prefix, PMC_FILE_C5 if args.config == "c5" else None) if args.config in ("headline", "c5") and (mode_key == "exact" or args.config == "c5") else None,
+                                "traffic_note": f"HBM bytes per launch, launch-weighted mean over this layout's tile-shape variants, from the committed PMC passes (profiles/{PMC_FILE_C5 if args.config == 'c5' else PMC_FILE}); not collected live",
                                 "avg_launch_us": round(1000.0 * gemms[dom]["ms"] / gemms[dom]["launches"], 2),
                                 "launches_per_step": gemms[dom]["launches"] / args.steps,
                                 "all_gemm_layouts": {k[1]: {"TFLOP/s": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),

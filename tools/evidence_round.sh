@@ -5,7 +5,12 @@ TAG=$1
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT && python -c "import __graft_entry__ as g; g.smoke()" || exit 1
 cd $ROOT && bash tools/gpu_round.sh $TAG || exit 1
-bash tools/pmc_traffic.sh ${TAG} || exit 1
+bash tools/pmc_traffic.sh ${TAG} "" || exit 1
+bash tools/pmc_traffic.sh ${TAG} _c5 --config c5 || exit 1
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_prof_c5 -o p -- python3 $ROOT/bench.py --config c5 --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timing --serial > $ROOT/gpurun_out/${TAG}_prof_c5.log 2>&1
+find $ROOT/gpurun_out/${TAG}_prof_c5 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $ROOT/gpurun_out/${TAG}_kernel_stats_c5.csv
+find $ROOT/gpurun_out/${TAG}_prof_c5 -name "*kernel_trace.csv" -delete
 cd $ROOT
 for c in c2 c3 c4 c5; do timeout -k 10 300 python bench.py --config $c --steps 8 --warmup 3 > gpurun_out/${TAG}_bench_$c.json 2> gpurun_out/${TAG}_bench_$c.err || tail -3 gpurun_out/${TAG}_bench_$c.err; done
 timeout -k 10 300 python bench.py --config c5 --reference-quirk --steps 8 --warmup 3 > gpurun_out/${TAG}_bench_c5_quirk.json 2>/dev/null
