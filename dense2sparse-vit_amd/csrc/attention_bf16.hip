@@ -48,14 +48,16 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const QT* __restr
     __shared__ __attribute__((aligned(16))) __bf16 Vt[DH * VP];      // [d][pos(key)]
     extern __shared__ __attribute__((aligned(16))) float cls_s[];    // [n] raw scaled scores of query 0 (block 0 only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    int bx, by;
+    xcd_remap_2d(bx, by);      // all blocks of one head on one XCD (shared K / V / Q / dO panels stay in its L2)
+    const int b = by / H, h = by % H;
     const long ld = 3L * H * DH;
     const QT* qb = qkv + (long)b * n * ld + h * DH;
     const QT* kb = qb + (long)H * DH;
     const QT* vb = kb + (long)H * DH;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = bx * 128 + wave * 32;
     const bool active = q0 < n;
-    const bool want_cls = cls_row != nullptr && blockIdx.x == 0 && wave == 0;
+    const bool want_cls = cls_row != nullptr && bx == 0 && wave == 0;
 
     // B operand of S^T = K Q^T: this lane's query, d = 16 kk + 8 half + j, scaled, as bf16
     bf16x8 qf[4];
@@ -273,13 +275,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const QT* __re
     __shared__ __attribute__((aligned(16))) __bf16 Vs[32 * KP];
     __shared__ __attribute__((aligned(16))) __bf16 Kt[DH * VP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    int bx, by;
+    xcd_remap_2d(bx, by);      // all blocks of one head on one XCD (shared K / V / Q / dO panels stay in its L2)
+    const int b = by / H, h = by % H;
     const long ld = 3L * H * DH, ldo = (long)H * DH;
     const QT* qb = qkv + (long)b * n * ld + h * DH;
     const QT* kb = qb + (long)H * DH;
     const QT* vb = kb + (long)H * DH;
     const float* dob = dout + (long)b * n * ldo + h * DH;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = bx * 128 + wave * 32;
     const bool active = q0 < n, qok = q0 + l31 < n;
     bf16x8 qf[4], dof[4];
     row_frags(qb, ld, q0 + l31, n, half, scale, qf);
@@ -329,7 +333,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const QT* __r
     __shared__ __attribute__((aligned(16))) __bf16 Dt[DH * VP];
     __shared__ float lse_s[32], dl_s[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    int bx, by;
+    xcd_remap_2d(bx, by);      // all blocks of one head on one XCD (shared K / V / Q / dO panels stay in its L2)
+    const int b = by / H, h = by % H;
     const long ld = 3L * H * DH, ldo = (long)H * DH;
     const QT* qb = qkv + (long)b * n * ld + h * DH;
     const QT* kb = qb + (long)H * DH;
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const QT* __r
     const float* dob = dout + (long)b * n * ldo + h * DH;
     const float* lse_b = lse + ((long)b * H + h) * n;
     const float* dl_b = delta + ((long)b * H + h) * n;
-    const int k0 = blockIdx.x * 128 + wave * 32;
+    const int k0 = bx * 128 + wave * 32;
     const bool active = k0 < n, kok = k0 + l31 < n;
     bf16x8 kf[4], vf[4];
     row_frags(kb, ld, k0 + l31, n, half, scale, kf);     // scaled copy: only the scores use it

@@ -126,20 +126,22 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float cls_s[];  // [n] raw scaled scores of query 0 (block 0 only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int H = a.H;
-    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    int bx, by;
+    xcd_remap_2d(bx, by);      // all blocks of one head on one XCD (shared K / V / Q / dO panels stay in its L2)
+    const int b = by / H, h = by % H;
     const long ld = 3L * H * DH;
     const int row_base = VARLEN ? a.cu[b] : 0;
     const int n = VARLEN ? a.cu[b + 1] - row_base : a.n;
-    if (VARLEN && (int)blockIdx.x * 128 >= n) return;                // block-uniform: this image has no queries in this tile
+    if (VARLEN && bx * 128 >= n) return;                // block-uniform: this image has no queries in this tile
     const long tok0 = VARLEN ? (long)row_base : (long)b * n;       // first token row of the image
     const float* qb = a.qkv + tok0 * ld + h * DH;
     const float* kb = qb + (long)H * DH;
     const float* vb = kb + (long)H * DH;
     const float* polb = POLICY ? a.policy + (long)b * n : nullptr;
     const float scale = a.scale;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = bx * 128 + wave * 32;
     const bool active = q0 < n;
-    const bool want_cls = a.cls_row != nullptr && blockIdx.x == 0 && wave == 0;
+    const bool want_cls = a.cls_row != nullptr && bx == 0 && wave == 0;
     const int qi = q0 + l31;
 
     f32x4 qreg[8];
@@ -291,13 +293,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const float* __rest
     __shared__ __attribute__((aligned(16))) float Vs[32 * PITCH];
     __shared__ float pol_s[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    int bx, by;
+    xcd_remap_2d(bx, by);      // all blocks of one head on one XCD (shared K / V / Q / dO panels stay in its L2)
+    const int b = by / H, h = by % H;
     const long ld = 3L * H * DH, ldo = (long)H * DH;
     const float* qb = qkv + (long)b * n * ld + h * DH;
     const float* kb = qb + (long)H * DH;
     const float* vb = kb + (long)H * DH;
     const float* dob = dout + (long)b * n * ldo + h * DH;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = bx * 128 + wave * 32;
     const bool active = q0 < n;
 
     f32x4 qreg[8], doreg[8];
@@ -371,7 +375,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
     __shared__ __attribute__((aligned(16))) float Ds[32 * PITCH];
     __shared__ float lse_s[32], dl_s[32], ci_s[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    int bx, by;
+    xcd_remap_2d(bx, by);      // all blocks of one head on one XCD (shared K / V / Q / dO panels stay in its L2)
+    const int b = by / H, h = by % H;
     const long ld = 3L * H * DH, ldo = (long)H * DH;
     const float* qb = qkv + (long)b * n * ld + h * DH;
     const float* kb = qb + (long)H * DH;
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
     const float* dob = dout + (long)b * n * ldo + h * DH;
     const float* lse_b = lse + ((long)b * H + h) * n;
     const float* dl_b = delta + ((long)b * H + h) * n;
-    const int k0 = blockIdx.x * 128 + wave * 32;
+    const int k0 = bx * 128 + wave * 32;
     const bool active = k0 < n;
 
     f32x4 kreg[8], vreg[8];

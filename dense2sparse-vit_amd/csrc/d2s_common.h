@@ -50,3 +50,20 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+
+// XCD-aware remap of a 2-D grid.  Workgroups are handed to the 8 XCDs round-robin in linear id order (x fastest), so the blockIdx.x tiles
+// of one blockIdx.y row - the query (key) blocks of one attention head, which all stream the same K / V (Q / dO) panels - would land on
+// different XCDs, each pulling its own copy of the panels into its L2.  This maps the hardware id to a virtual (bx, by) such that every
+// XCD owns a contiguous range of the x-fastest linear order (bijective, same construction as the GEMM tile order).
+__device__ __forceinline__ void xcd_remap_2d(int& bx, int& by) {
+#ifdef D2S_NO_XCD_REMAP_2D      // diagnostic build for the A/B (tools/attn_bench.py with D2S_LIB_PATH)
+    bx = (int)blockIdx.x; by = (int)blockIdx.y;
+    return;
+#endif
+    const int gx = (int)gridDim.x, total = gx * (int)gridDim.y;
+    const int L = (int)blockIdx.y * gx + (int)blockIdx.x;
+    const int xcd = L & 7, idx = L >> 3, q = total >> 3, r = total & 7;
+    const int V = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    by = V / gx;
+    bx = V - by * gx;
+}
