@@ -36,6 +36,7 @@ struct GemmArgs {
     // bf16 mode only (d2s_gemm_f32_bf16io): a16 = the A operand already rounded to bf16, dense [M][K] (K % 32 == 0) - no conversion pass;
     // c16 = where to put a bf16 copy of the result, dense [M][N] (N % 32 == 0): the next GEMM's a16
     const void* a16; void* c16;
+    const void* b16;   // bf16 mode: the B operand already in bf16, [N][K] k-contiguous whatever the layout (a cached weight, or W^T for dgrad)
 };
 
 template <int EPI, int MT, int NT>

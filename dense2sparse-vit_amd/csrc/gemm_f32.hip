@@ -926,9 +926,10 @@ size_t d2s_gemm_f32_workspace_bytes(int layout, int M, int N, int K, int mode) {
 static int gemm_impl(int layout, const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                      int K, int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, int aux_rows,
                      int remap_rows_per_img, int remap_skip, int accumulate, void* workspace, size_t workspace_bytes,
-                     hipStream_t stream, float* colsum_out, int mode, const void* a16 = nullptr, void* c16 = nullptr) {
+                     hipStream_t stream, float* colsum_out, int mode, const void* a16 = nullptr, void* c16 = nullptr, const void* b16 = nullptr) {
     // layout 2 (weight gradient): a16 is the bf16 form of the SECOND operand (the layer input x); B may then be NULL
-    if ((!A && !(a16 && layout != 2)) || (!B && !(a16 && layout == 2)) || (!C && !c16) || M <= 0 || N <= 0 || K <= 0 || layout < 0 || layout > 2 || mode < 0 || mode > 2) return D2S_ERR_ARG;
+    if (b16 && (mode != 2 || layout == 2 || K % 32 != 0 || !aligned16(b16))) return D2S_ERR_ARG;
+    if ((!A && !(a16 && layout != 2)) || (!B && !(a16 && layout == 2) && !b16) || (!C && !c16) || M <= 0 || N <= 0 || K <= 0 || layout < 0 || layout > 2 || mode < 0 || mode > 2) return D2S_ERR_ARG;
     if ((a16 || c16) && (mode != 2 || (layout != 2 && accumulate) || remap_rows_per_img > 0)) return D2S_ERR_ARG;   // bf16 operands / copies exist in bf16 mode only
     if (layout == 2 && (c16 || (a16 && !bf16_wgrad(mode)))) return D2S_ERR_ARG;
     if (layout == 2 && a16) {
@@ -944,7 +945,7 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
     p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.aux_rows = aux_rows > 0 ? aux_rows : 1;
     p.remap_rows_per_img = remap_rows_per_img; p.remap_skip = remap_skip;
     p.colsum = nullptr; p.colsum_accumulate = accumulate;
-    p.a16 = a16; p.c16 = c16;
+    p.a16 = a16; p.c16 = c16; p.b16 = b16;
     {
         p.stagger = 0;
         p.vec_epilogue = 0;
@@ -1062,12 +1063,14 @@ int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb,
 // [M][K] - the call then skips its conversion pass over A, which must still hold the same values in fp32; c_bf16 (optional) = a dense
 // [M][N] bf16 copy of the result written by the same epilogue - the a_bf16 of the next GEMM.  NT / NN layouts, K % 32 == 0 for a_bf16,
 // N % 32 == 0 for c_bf16.  With a_bf16 given A may be NULL, with c_bf16 given C may be NULL (forward-only passes that keep no fp32 form).
+// b_bf16 (optional) = the B operand in bf16, ALWAYS [N][K] k-contiguous (for layout 1, dx = dy W, that is W^T): a cached weight
+// (d2s_convert_bf16 once per optimiser step, or once for a frozen model) - the call then skips its per-call conversion of B; B may be NULL.
 int d2s_gemm_f32_bf16io(int layout, const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
-                        int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, const void* a_bf16, void* c_bf16,
-                        void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                        int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, const void* a_bf16, const void* b_bf16,
+                        void* c_bf16, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (layout == 2) return D2S_ERR_ARG;      // weight gradients with a bf16 input: d2s_linear_wgrad_f32_bf16x
     return gemm_impl(layout, A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, aux, ldaux, aux_out, 0, 0, 0, 0, workspace, workspace_bytes,
-                     stream, nullptr, 2, a_bf16, c_bf16);
+                     stream, nullptr, 2, a_bf16, c_bf16, b_bf16);
 }
 
 // nn.Linear backward w.r.t. its parameters in one pass over dy:  dW[n_out, n_in] (+)= dy^T x,  db[n_out] (+)= column sums of dy.

@@ -35,6 +35,20 @@ __device__ __forceinline__ void split3(float a, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)(r1 - (float)m);
 }
 
+// ---- flat fp32 -> bf16 copy (weights: a whole parameter arena, or one frozen weight, once; d2s_convert_bf16) ----------------------------
+__global__ __launch_bounds__(256) void convert_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 7 < n) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + i), b = *reinterpret_cast<const f32x4*>(src + i + 4);
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = (__bf16)a[j]; v[4 + j] = (__bf16)b[j]; }
+        *reinterpret_cast<bf16x8*>(dst + i) = v;
+    } else {
+        for (long j = i; j < n; ++j) dst[j] = (__bf16)src[j];
+    }
+}
+
 // ---- stage 1a: row-major source [R][K] (ld) -> pieces [SPLIT][R][Kp] -------------------------------------------------------
 template <int SPLIT>
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, long ld, __bf16* __restrict__ dst, int R, int K,
@@ -575,6 +589,9 @@ int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace,
     if ((long)p.M * Kp * 2 >= (1L << 32) || (long)p.N * Kp * 2 >= (1L << 32)) return D2S_ERR_ARG;   // per-thread byte offsets are 32-bit
     __bf16* Ap = static_cast<__bf16*>(workspace);
     __bf16* Bp = reinterpret_cast<__bf16*>(static_cast<unsigned char*>(workspace) + align256((size_t)split * p.M * Kp * sizeof(__bf16)));
+    // the caller's cached bf16 form of the B operand, always [N][K] k-contiguous (for the dgrad layout: W^T), K % 32 == 0
+    const bool have_b16 = p.b16 != nullptr && split == 1;
+    if (have_b16) Bp = static_cast<__bf16*>(const_cast<void*>(p.b16));
     const long ea = (long)p.M * (Kp / 4), eb = (long)p.N * (Kp / 4);
     dim3 block(256);
     // The activation operand can be converted inside the matrix kernel (read as fp32 with 16-byte loads, no split pass over it) instead
@@ -615,7 +632,8 @@ int launch_split_gemm(const GemmArgs& p, int b_cols, int split, void* workspace,
         else hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)((eb + 255) / 256)), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
     } else {
         if (!af32 && !have_a16) hipLaunchKernelGGL(split_rows_kernel<1>, dim3((unsigned)((ea + 255) / 256)), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA);
-        if (b_cols) hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB, static_cast<float*>(nullptr));
+        if (have_b16) { /* nothing to convert */ }
+        else if (b_cols) hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB, static_cast<float*>(nullptr));
         else hipLaunchKernelGGL(split_rows_kernel<1>, dim3((unsigned)((eb + 255) / 256)), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB);
     }
     if (dma_shape && !af32) {
@@ -694,7 +712,7 @@ int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_
         hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.B, p.ldb, Bp, p.N, p.K, Kp, p.vecB, static_cast<float*>(nullptr));
     GemmArgs pv = p;                      // p.C / p.ldc / p.slab_stride / p.k_per_slice / p.epi were set by the caller
     pv.vec_epilogue = (epilogue_vec_ok(p) && (p.slab_stride % 4 == 0)) ? 1 : 0;
-    pv.a16 = nullptr; pv.c16 = nullptr;
+    pv.a16 = nullptr; pv.c16 = nullptr; pv.b16 = nullptr;
     PieceArgs q{Ap, Bp, Kp};
     if (split_tn_use_dma(p.M, p.N, p.K) && pv.vec_epilogue && p.k_per_slice % 64 == 0) {
         launch_dma<4, 64, 2>(pv, q, stream);
@@ -714,3 +732,10 @@ extern "C" int d2s_debug_read_stamps(unsigned long long* host_out, int n_wg) {
 #endif
 
 }  // namespace d2s_gemm
+
+// dst[i] = bf16(src[i]), i < n: the bf16 form of a weight (or of a whole parameter arena) for d2s_gemm_f32_bf16io's b_bf16
+extern "C" int d2s_convert_bf16(const float* src, void* dst, long n, hipStream_t stream) {
+    if (!src || !dst || n <= 0 || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 15)) return D2S_ERR_ARG;
+    hipLaunchKernelGGL(convert_bf16_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, stream, src, static_cast<__bf16*>(dst), n);
+    return d2s_check_launch();
+}

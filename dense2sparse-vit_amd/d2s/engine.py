@@ -142,6 +142,10 @@ class FusedAdamW:
         if self._wt is None:
             self._wt = ops.TransposedArena(a.params, list(zip(a.params_list, a.offsets)))
         self._wt.refresh()
+        if ops.bf16_io() and ops._BF16_WEIGHTS:      # bf16 mode: the GEMMs read bf16 mirrors of W and W^T made here, once per step
+            if getattr(self, "_w16", None) is None:
+                self._w16 = ops.Bf16Weights(a.params, list(zip(a.params_list, a.offsets)), self._wt)
+            self._w16.refresh()
 
     def zero_grad(self):
         for p in self.arena.params_list:

@@ -18,7 +18,8 @@ P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ct
 _SIGS = {
     "d2s_gemm_f32_workspace_bytes": (Z, [I, I, I, I, I]),
     "d2s_gemm_f32": (I, [I, P, L, P, L, P, L, I, I, I, I, P, P, L, P, I, I, I, I, I, P, Z]),
-    "d2s_gemm_f32_bf16io": (I, [I, P, L, P, L, P, L, I, I, I, I, P, P, L, P, P, P, P, Z]),
+    "d2s_gemm_f32_bf16io": (I, [I, P, L, P, L, P, L, I, I, I, I, P, P, L, P, P, P, P, P, Z]),
+    "d2s_convert_bf16": (I, [P, P, L]),
     "d2s_linear_wgrad_workspace_bytes": (Z, [I, I, I, I]),
     "d2s_linear_wgrad_f32": (I, [P, L, P, L, P, L, P, I, I, I, I, I, P, Z]),
     "d2s_linear_wgrad_f32_bf16x": (I, [P, L, P, L, P, L, P, I, I, I, I, P, Z]),

@@ -71,8 +71,66 @@ def shadow_take(t):
     return e[2]
 
 
+# bf16 weights.  A weight's bf16 form is made once and reused: for the weights of a parameter arena (the trained model) d2s.engine converts the
+# whole arena - and the arena of W^T copies - in one launch each at the start of every step (Bf16Weights.refresh); a weight outside any
+# arena that does not require gradients (the frozen teacher) is converted on first use and again only when its version counter moves.
+# Anything else (a free-standing trainable tensor) has no safe invalidation signal and is converted inside each GEMM call as before.
+_W16 = {}                       # (data_ptr, transposed) -> (weakref to the weight or None for arena entries, epoch, version, shape, bf16 tensor)
+_BF16_WEIGHTS = os.environ.get("D2S_BF16_WEIGHT_CACHE", "1") != "0"
+
+
+def bf16_weight(W, transposed=False):
+    """bf16 [N][K] form of the B operand of y = x W^T (transposed=False: W itself) or of dx = dy W (transposed=True: W^T), or None."""
+    if not (_BF16_WEIGHTS and _BF16_IO and W.is_cuda and W.dim() == 2 and W.shape[0 if transposed else 1] % 32 == 0):
+        return None
+    ent = _W16.get((W.data_ptr(), transposed))
+    shape = tuple(W.shape)
+    if ent is not None and ent[2] == W._version and ent[3] == shape:
+        if ent[0] is None:
+            if ent[1] == weights_epoch:
+                return ent[4]                       # arena weight, converted at the start of this step
+        elif ent[0]() is W:
+            return ent[4]                           # frozen weight, unchanged since its conversion
+    if transposed or W.requires_grad or _in_weight_arena(W.data_ptr()):
+        return None
+    import weakref
+    t16 = torch.empty(shape, dtype=torch.bfloat16, device=W.device)
+    lib.call("d2s_convert_bf16", lib.ptr(W), lib.ptr(t16), W.numel())
+    if len(_W16) > 4096:
+        _W16.clear()
+    _W16[(W.data_ptr(), False)] = (weakref.ref(W), -1, W._version, shape, t16)
+    return t16
+
+
+class Bf16Weights:
+    """bf16 mirrors of a parameter arena and of its W^T arena (TransposedArena), each refreshed by ONE launch per step."""
+
+    def __init__(self, arena_params, weights, transposed_arena):
+        self.src, self.tsrc = arena_params, transposed_arena.dst
+        self.dst = torch.empty(arena_params.numel(), dtype=torch.bfloat16, device=arena_params.device)
+        self.tdst = torch.empty(self.tsrc.numel(), dtype=torch.bfloat16, device=arena_params.device)
+        self.entries = []
+        toff = 0
+        for w, off in weights:
+            if w.dim() != 2:
+                continue
+            R, C = w.shape
+            self.entries.append((w, self.dst[off:off + R * C].view(R, C), self.tdst[toff:toff + R * C].view(C, R)))
+            toff += R * C
+
+    def refresh(self):
+        """call after TransposedArena.refresh() of the same step"""
+        lib.call("d2s_convert_bf16", lib.ptr(self.src), lib.ptr(self.dst), self.src.numel())
+        lib.call("d2s_convert_bf16", lib.ptr(self.tsrc), lib.ptr(self.tdst), self.tsrc.numel())
+        for w, w16, wt16 in self.entries:
+            shape = tuple(w.shape)
+            if (w.data_ptr() * 2) % 16 == 0 and w16.data_ptr() % 16 == 0 and wt16.data_ptr() % 16 == 0:
+                _W16[(w.data_ptr(), False)] = (None, weights_epoch, w._version, shape, w16)
+                _W16[(w.data_ptr(), True)] = (None, weights_epoch, w._version, shape, wt16)
+
+
 def gemm(layout, A, lda, B, ldb, C, ldc, M, N, K, epi=EPI_NONE, bias=None, aux=None, ldaux=0, aux_out=None, aux_rows=0,
-         remap_rows=0, remap_skip=0, accumulate=False, a16=None, c16=None):
+         remap_rows=0, remap_skip=0, accumulate=False, a16=None, c16=None, b16=None):
     mode = get_gemm_mode()
     qk = (layout, M, N, K, mode)
     need = _WS_NEED.get(qk)
@@ -80,12 +138,13 @@ def gemm(layout, A, lda, B, ldb, C, ldc, M, N, K, epi=EPI_NONE, bias=None, aux=N
         need = _WS_NEED[qk] = lib.query("d2s_gemm_f32_workspace_bytes", layout, M, N, K, mode)
     dev = C.device if C is not None else c16.device
     ws = workspace(need, dev) if need else None
-    if a16 is not None or c16 is not None:
+    if a16 is not None or c16 is not None or b16 is not None:
         assert mode == GEMM_BF16 and not accumulate and remap_rows == 0 and aux_rows == 0
+        assert b16 is None or (b16.dtype == torch.bfloat16 and b16.is_contiguous() and tuple(b16.shape) == (N, K)), "b16 must be dense bf16 [N, K]"
         assert a16 is None or (a16.dtype == torch.bfloat16 and a16.is_contiguous() and tuple(a16.shape) == (M, K)), "a16 must be dense bf16 [M, K]"
         assert c16 is None or (c16.dtype == torch.bfloat16 and c16.is_contiguous() and tuple(c16.shape) == (M, N)), "c16 must be dense bf16 [M, N]"
         lib.call("d2s_gemm_f32_bf16io", layout, lib.ptr(A), lda, lib.ptr(B), ldb, lib.ptr(C), ldc, M, N, K, epi, lib.ptr(bias),
-                 lib.ptr(aux), ldaux, lib.ptr(aux_out), lib.ptr(a16), lib.ptr(c16), lib.ptr(ws), ws.numel() if ws is not None else 0)
+                 lib.ptr(aux), ldaux, lib.ptr(aux_out), lib.ptr(a16), lib.ptr(b16), lib.ptr(c16), lib.ptr(ws), ws.numel() if ws is not None else 0)
         return C
     lib.call("d2s_gemm_f32", layout, lib.ptr(A), lda, lib.ptr(B), ldb, lib.ptr(C), ldc, M, N, K, epi, lib.ptr(bias),
              lib.ptr(aux), ldaux, lib.ptr(aux_out), aux_rows, remap_rows, remap_skip, int(accumulate), mode, lib.ptr(ws),
@@ -106,7 +165,8 @@ def linear_fwd(x, W, bias=None, epi=None, aux=None, aux_out=None, out=None, a16=
         out = torch.empty((M, N), dtype=torch.float32, device=W.device)
     if epi is None:
         epi = EPI_BIAS if bias is not None else EPI_NONE
-    return gemm(NT, x, K, W, K, out, N, M, N, K, epi, bias, aux, N if aux is not None else 0, aux_out, a16=a16, c16=c16)
+    b16 = bf16_weight(W) if get_gemm_mode() == GEMM_BF16 else None
+    return gemm(NT, x, K, W, K, out, N, M, N, K, epi, bias, aux, N if aux is not None else 0, aux_out, a16=a16, c16=c16, b16=b16)
 
 
 # ---- k-contiguous copies W^T of Linear weights for the input-gradient GEMM ----
@@ -199,8 +259,10 @@ def linear_dgrad(dy, W, epi=EPI_NONE, aux=None, out=None, a16=None, c16=None):
     K = W.shape[1]
     if out is None:
         out = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-    if a16 is not None or c16 is not None:
-        return gemm(NN, dy, N, W, K, out, K, M, K, N, epi, None, aux, K if aux is not None else 0, a16=a16, c16=c16)
+    if get_gemm_mode() == GEMM_BF16:
+        wt16 = bf16_weight(W, transposed=True)      # [K][N] = W^T in bf16: the k-contiguous B operand of dx = dy W
+        if a16 is not None or c16 is not None or wt16 is not None:
+            return gemm(NN, dy, N, W, K, out, K, M, K, N, epi, None, aux, K if aux is not None else 0, a16=a16, c16=c16, b16=wt16)
     if get_gemm_mode() == GEMM_EXACT and M >= _DGRAD_NT_MIN_ROWS and (N % 16 == 0) and (K % 4 == 0) and _in_weight_arena(W.data_ptr()):
         return gemm(NT, dy, N, transposed_weight(W), N, out, K, M, K, N, epi, None, aux, K if aux is not None else 0)
     return gemm(NN, dy, N, W, K, out, K, M, K, N, epi, None, aux, K if aux is not None else 0)

@@ -56,8 +56,12 @@ int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb,
  * bf16 copy of the result, N % 32 == 0, written by the same epilogue - the a_bf16 of the next GEMM (C may then be NULL).  Producers of
  * a_bf16 other than a GEMM: d2s_layernorm_fwd_bf16out, d2s_attn_fwd_bf16_bf16out.  NT / NN layouts; workspace as d2s_gemm_f32 in mode 2. */
 int d2s_gemm_f32_bf16io(int layout, const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
-                        int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, const void* a_bf16, void* c_bf16,
-                        void* workspace, size_t workspace_bytes, d2s_stream_t stream);
+                        int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, const void* a_bf16, const void* b_bf16,
+                        void* c_bf16, void* workspace, size_t workspace_bytes, d2s_stream_t stream);
+/* dst[i] = bf16(src[i]): the bf16 form of a weight - or of a whole parameter arena in one launch - for b_bf16 above (b_bf16 is always
+ * [N][K] k-contiguous: the weight itself for layout 0, W^T for layout 1; made once per optimiser step, once ever for a frozen model;
+ * B may then be NULL) */
+int d2s_convert_bf16(const float* src, void* dst, long n, d2s_stream_t stream);
 /* nn.Linear parameter gradients in one pass over dy (autograd of F.linear at vit_models/dynamic_vit.py:169-175,218,231,491-531):
  * dW[n_out,n_in] (+)= dy[tokens,n_out]^T x[tokens,n_in];  db[n_out] (+)= column sums of dy (db may be NULL).  Exact fp32 MFMA,
  * deterministic split-K over the token rows; the bias gradient is folded out of the dy tiles the GEMM streams anyway. */

@@ -376,6 +376,19 @@ def test_gemm_bf16_io(ops, M, N, K):
         np.testing.assert_allclose(z.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
         np.testing.assert_allclose(h.cpu().numpy(), F.gelu(ref).numpy(), rtol=1e-4, atol=2e-5)
         assert torch.equal(c16, h.bfloat16())
+        # the weight handed over in bf16 (d2s_convert_bf16 once, instead of a conversion inside every call): identical result
+        from d2s import lib
+        w16 = torch.empty((N, K), dtype=torch.bfloat16, device=_dev())
+        lib.call("d2s_convert_bf16", lib.ptr(wd), lib.ptr(w16), wd.numel())
+        assert torch.equal(w16, wd.bfloat16())
+        out_b = torch.empty((M, N), device=_dev())
+        ops.gemm(ops.NT, xd, K, None, K, out_b, N, M, N, K, ops.EPI_BIAS, bd, a16=x16, b16=w16)
+        assert torch.equal(out_b, got)
+        wt16 = wd.t().contiguous().bfloat16()                     # [K][N]: the k-contiguous B operand of dx = dy W
+        dxb = torch.empty((M, K), device=_dev())
+        dyd0 = _rand("idy", (M, N), seed=M + N).to(_dev())
+        ops.gemm(ops.NN, dyd0, N, None, K, dxb, K, M, K, N, ops.EPI_NONE, None, b16=wt16)
+        np.testing.assert_allclose(dxb.cpu().numpy(), (dyd0.cpu().bfloat16().double() @ wr.double()).float().numpy(), rtol=2e-5, atol=2e-4)
         # input-gradient layout: dx = dy @ W with a16 = bf16(dy) and a bf16 copy of dx
         dy = _rand("idy", (M, N), seed=M + N)
         dref = (dy.bfloat16().double() @ wr.double()).float()
@@ -426,11 +439,11 @@ def test_bf16_io_rejected_outside_bf16_mode(ops):
     x2, w2 = _rand("rx2", (256, 40)).to(_dev()), _rand("rw2", (128, 40)).to(_dev())
     with pytest.raises(RuntimeError):
         lib.call("d2s_gemm_f32_bf16io", 0, lib.ptr(x2), 40, lib.ptr(w2), 40, lib.ptr(out), 128, 256, 128, 40, 0, None, None, 0, None,
-                 lib.ptr(x2.bfloat16()), None, lib.ptr(ws), ws.numel())
+                 lib.ptr(x2.bfloat16()), None, None, lib.ptr(ws), ws.numel())
     # the weight-gradient layout has no bf16 side channel
     with pytest.raises(RuntimeError):
         lib.call("d2s_gemm_f32_bf16io", 2, lib.ptr(x), 64, lib.ptr(w), 64, lib.ptr(out), 128, 256, 128, 64, 0, None, None, 0, None,
-                 lib.ptr(x.bfloat16()), None, lib.ptr(ws), ws.numel())
+                 lib.ptr(x.bfloat16()), None, None, lib.ptr(ws), ws.numel())
 
 
 @pytest.mark.parametrize("rows,D", [(197 * 3, 384), (1000, 768), (77, 192), (130, 1536)])
