@@ -96,6 +96,7 @@ def bf16_weight(W, transposed=False):
     import weakref
     t16 = torch.empty(shape, dtype=torch.bfloat16, device=W.device)
     lib.call("d2s_convert_bf16", lib.ptr(W), lib.ptr(t16), W.numel())
+    torch.cuda.current_stream().synchronize()       # once per frozen weight: later calls may read the copy from any stream
     if len(_W16) > 4096:
         _W16.clear()
     _W16[(W.data_ptr(), False)] = (weakref.ref(W), -1, W._version, shape, t16)
@@ -124,7 +125,7 @@ class Bf16Weights:
         lib.call("d2s_convert_bf16", lib.ptr(self.tsrc), lib.ptr(self.tdst), self.tsrc.numel())
         for w, w16, wt16 in self.entries:
             shape = tuple(w.shape)
-            if (w.data_ptr() * 2) % 16 == 0 and w16.data_ptr() % 16 == 0 and wt16.data_ptr() % 16 == 0:
+            if w16.data_ptr() % 16 == 0 and wt16.data_ptr() % 16 == 0:
                 _W16[(w.data_ptr(), False)] = (None, weights_epoch, w._version, shape, w16)
                 _W16[(w.data_ptr(), True)] = (None, weights_epoch, w._version, shape, wt16)
 

@@ -218,3 +218,30 @@ def test_param_groups_and_lr_schedule_match_reference_fixture():
         engine.adjust_learning_rate(opt, m, epoch, a["epochs"], a["lr"], a["min_lr"], a["warmup_steps"])
         assert abs(opt.lrs[0] - want["lr"]["predictor"]) <= 1e-12 and abs(opt.lrs[1] - want["lr"]["base_decay"]) <= 1e-12, epoch
         assert sorted(n for n, p in m.named_parameters() if not p.requires_grad) == want["frozen"], epoch
+
+
+def test_bf16_data_path_host_logic():
+    """Host side of the bf16 data path, no GPU needed.  (1) The one-entry registry that carries a gradient's bf16 copy from one block's
+    backward to the previous block's: a hit needs the same address, element count and version counter, an entry is used at most once,
+    and a rewritten gradient misses.  (2) The bf16 side channels are refused outside the bf16 arithmetic mode (assertion before any
+    library call).  (3) No cached bf16 weight is ever offered for a CPU tensor or a free-standing trainable one."""
+    from d2s import ops
+    g = torch.zeros(4, 6)
+    g16 = torch.zeros(4, 6, dtype=torch.bfloat16)
+    ops.shadow_put(g, g16)
+    assert ops.shadow_take(g.view(24)) is g16            # a view of the same storage (what autograd hands to the next Function)
+    assert ops.shadow_take(g) is None                    # used at most once
+    ops.shadow_put(g, g16)
+    g.add_(1.0)                                          # the gradient was rewritten (an accumulation, a hook): version counter moved
+    assert ops.shadow_take(g) is None
+    ops.shadow_put(g, g16)
+    assert ops.shadow_take(torch.zeros(4, 6)) is None    # another tensor
+    assert ops.shadow_take(g) is None                    # ... and any lookup empties the registry
+    ops.shadow_put(g, g16)
+    assert ops.shadow_take(g[:2]) is None                # same address, other element count
+    assert ops.get_gemm_mode() == ops.GEMM_EXACT and not ops.bf16_io()
+    with pytest.raises(AssertionError):
+        ops.gemm(ops.NT, torch.zeros(32, 32), 32, torch.zeros(32, 32), 32, torch.zeros(32, 32), 32, 32, 32, 32,
+                 a16=torch.zeros(32, 32, dtype=torch.bfloat16))
+    w = torch.nn.Parameter(torch.zeros(64, 64))
+    assert ops.bf16_weight(w) is None and ops.bf16_weight(w.detach()) is None and ops.bf16_weight(w, transposed=True) is None
