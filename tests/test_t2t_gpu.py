@@ -234,3 +234,48 @@ def test_pruned_t2t_14_full_size_step_properties():
         _, half = ts.forward_losses(x[:32].contiguous(), y[:32].contiguous())
     np.testing.assert_array_equal(half["kept"][0].cpu().numpy(), kept[:32])
     np.testing.assert_allclose(half["logits_s"].cpu().numpy(), runs[0][2][:32].cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_pruned_t2t_14_bf16_mode_step():
+    """Config 4's model through the bf16 arithmetic mode and its bf16 data path (the backbone blocks are the same BlockFn as DeiT's;
+    the T2T stages keep their fp32 kernels): two identical steps are bit-identical, the teacher's logits stay within bf16 distance of the
+    exact mode's (rtol 2e-2 of the largest logit), and the kept / dropped ids still partition the 196 tokens."""
+    import vit_models
+    from d2s import ops
+    from d2s.engine import TrainStep
+    dev = torch.device("cuda:0")
+    args = types.SimpleNamespace(keep_ratios=[0.5], mask_loss_type="kl_div", mixup=0.0, patch_score_threshold=None, step=0)
+    B = 16
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn((B, 3, 224, 224), device=dev, generator=g)
+    y = torch.randint(0, 1000, (B,), device=dev, generator=g)
+
+    def run(mode, reps):
+        ops.set_gemm_mode(mode)
+        try:
+            torch.manual_seed(0)
+            student = vit_models.t2t_vit_14_student([3], [0.5]).to(dev)
+            teacher = vit_models.t2t_vit_14_teacher().to(dev)
+            ts = TrainStep(student, teacher, args)
+            out = []
+            for _ in range(reps):
+                student.train()
+                loss, info = ts.forward_losses(x, y)
+                ts.opt.zero_grad()
+                loss.backward()
+                torch.cuda.synchronize()
+                out.append((float(loss.detach()), info["kept"][0].clone(), info["logits_t"].clone(), ts.arena.grads.clone(),
+                            student.dropped_token_indices[0].clone()))
+        finally:
+            ops.set_gemm_mode(ops.GEMM_EXACT)
+        return out
+
+    exact = run(ops.GEMM_EXACT, 1)
+    bf = run(ops.GEMM_BF16, 2)
+    assert bf[0][0] == bf[1][0] and torch.equal(bf[0][1], bf[1][1]) and torch.equal(bf[0][3], bf[1][3]), "bf16 mode is not deterministic"
+    assert np.isfinite(bf[0][0]) and torch.isfinite(bf[0][3]).all() and float(bf[0][3].abs().max()) > 0
+    lt = exact[0][2].cpu().numpy()
+    np.testing.assert_allclose(bf[0][2].cpu().numpy(), lt, rtol=2e-2, atol=2e-2 * float(np.abs(lt).max()))
+    np.testing.assert_allclose(bf[0][0], exact[0][0], rtol=2e-2)
+    kept, dropped = bf[0][1].cpu().numpy(), bf[0][4].cpu().numpy()
+    np.testing.assert_array_equal(np.sort(np.concatenate([kept, dropped], axis=1), axis=1), np.tile(np.arange(196), (B, 1)))
