@@ -319,8 +319,16 @@ class PredictorFn(torch.autograd.Function):
         x = x.contiguous()
         eps = 1e-5
         train = any(ctx.needs_input_grad)
-        h0, mean0, rstd0 = ops.layernorm_fwd(x, ops.skip_cls_map(n, D), params[0], params[1], M, D, eps, stats=train)
-        a1 = ops.linear_fwd(h0, params[2], params[3], epi=ops.EPI_BIAS_RELU)
+        # bf16 arithmetic mode: as in BlockFn, each LayerNorm in front of a bf16-mode Linear also (training: only) writes the bf16 form
+        # that GEMM multiplies; the weight gradients read it too.  The exact-fp32 tail keeps fp32 activations.
+        io = ops.bf16_io() and x.is_cuda and D % 32 == 0
+        if io:
+            h0, mean0, rstd0, h0h = ops.layernorm_fwd_bf16(x, ops.skip_cls_map(n, D), params[0], params[1], M, D, eps, stats=train, want_f32=False)
+            a1 = ops.linear_fwd(None, params[2], params[3], epi=ops.EPI_BIAS_RELU, a16=h0h)
+            h0 = h0h
+        else:
+            h0, mean0, rstd0 = ops.layernorm_fwd(x, ops.skip_cls_map(n, D), params[0], params[1], M, D, eps, stats=train)
+            a1 = ops.linear_fwd(h0, params[2], params[3], epi=ops.EPI_BIAS_RELU)
         C = a1.shape[1]
         cur = ops.half_mean_concat(a1, B, T, C)
         saved = [x, h0, mean0, rstd0, a1]
@@ -328,12 +336,17 @@ class PredictorFn(torch.autograd.Function):
         for j in range(nl):
             lw, lb, fw, fb = params[4 + 4 * j: 8 + 4 * j]
             width = cur.shape[1]
-            ln, mean, rstd = ops.layernorm_fwd(cur, ops.contiguous_map(M, width), lw, lb, M, width, eps, stats=train)
             last = j == nl - 1
+            exact_tail = j >= nl - 2
             # the predictor's tail (its last two Linear layers, D/2 -> D/4 -> 1: 0.3 % of its FLOPs), like the softmax and the selection
             # behind it, always runs in exact fp32 - also in the bf16 arithmetic mode (kept-id stability)
-            with ops.gemm_mode(ops.GEMM_EXACT if j >= nl - 2 else ops.get_gemm_mode()):
-                nxt = ops.linear_fwd(ln, fw, fb, epi=ops.EPI_BIAS if last else ops.EPI_BIAS_RELU)
+            if io and not exact_tail and width % 32 == 0:
+                _, mean, rstd, ln = ops.layernorm_fwd_bf16(cur, ops.contiguous_map(M, width), lw, lb, M, width, eps, stats=train, want_f32=False)
+                nxt = ops.linear_fwd(None, fw, fb, epi=ops.EPI_BIAS_RELU, a16=ln)
+            else:
+                ln, mean, rstd = ops.layernorm_fwd(cur, ops.contiguous_map(M, width), lw, lb, M, width, eps, stats=train)
+                with ops.gemm_mode(ops.GEMM_EXACT if exact_tail else ops.get_gemm_mode()):
+                    nxt = ops.linear_fwd(ln, fw, fb, epi=ops.EPI_BIAS if last else ops.EPI_BIAS_RELU)
             saved += [cur, ln, mean, rstd]
             cur = nxt
         scores = cur.view(B, T)
@@ -355,26 +368,36 @@ class PredictorFn(torch.autograd.Function):
         grads = [None] * np_
         want = [_need(ctx, 1 + i) for i in range(np_)]
         d = gscores.contiguous().view(M, 1)
+        d16 = None                      # bf16 copy of d, written by the LayerNorm backward that produced it, when the next GEMMs run in bf16
+        io = ops.bf16_io() and gscores.is_cuda
+
+        def xarg(t):                    # a saved layer input: fp32, or bf16 only (bf16 data path)
+            return (None, t) if t.dtype == torch.bfloat16 else (t, None)
         for j in reversed(range(nl)):
             cur, ln, mean, rstd = saved[5 + 4 * j: 9 + 4 * j]
             lw, lb, fw, fb = params[4 + 4 * j: 8 + 4 * j]
             base = 4 + 4 * j
             width = cur.shape[1]
+            lnx, ln16 = xarg(ln)
             # d is the gradient w.r.t. the pre-activation of layer j's Linear (the ReLU mask was applied upstream)
             with ops.gemm_mode(ops.GEMM_EXACT if j >= nl - 2 else ops.get_gemm_mode()):      # same arithmetic as the forward of this layer
-                grads[base + 2], grads[base + 3] = ops.linear_param_grads(d, ln, fw, fb, want[base + 2], want[base + 3])
-                dln = ops.linear_dgrad(d, fw)
+                grads[base + 2], grads[base + 3] = ops.linear_param_grads(d, lnx, fw, fb, want[base + 2], want[base + 3], x16=ln16)
+                dln = ops.linear_dgrad(d, fw, a16=d16 if ln16 is not None else None)
             dcur = torch.empty((M, width), dtype=torch.float32, device=dev)
+            # the layer below (j - 1) multiplies dcur in bf16 if it is a bf16-mode layer: its saved input is bf16 then
+            below_bf16 = io and j >= 1 and saved[5 + 4 * (j - 1) + 1].dtype == torch.bfloat16 and width % 32 == 0
+            d16 = ops.bf16_buffer(M, width, dev) if below_bf16 else None
             dlw = ops.grad_buffer(lw) if (want[base] or want[base + 1]) else None
             dlb = ops.grad_buffer(lb) if dlw is not None else None
             # cur is the ReLU output of layer j-1 for j >= 1 -> fold that ReLU's backward in; for j == 0 cur is the
             # split/mean/concat output and the mask is applied by half_mean_concat below
             ops.layernorm_bwd(cur, ops.contiguous_map(M, width), dln, lw, mean, rstd, dcur, None, dlw, dlb, M, width,
-                              relu_mask=(j >= 1))
+                              relu_mask=(j >= 1), dx16=d16)
             grads[base], grads[base + 1] = (dlw if want[base] else None), (dlb if want[base + 1] else None)
             d = dcur
         dz1 = ops.half_mean_concat(d, B, T, C, relu_mask_src=a1)
-        grads[2], grads[3] = ops.linear_param_grads(dz1, h0, params[2], params[3], want[2], want[3])
+        h0x, h016 = xarg(h0)
+        grads[2], grads[3] = ops.linear_param_grads(dz1, h0x, params[2], params[3], want[2], want[3], x16=h016)
         gx = None
         if _need(ctx, 0) or want[0] or want[1]:
             dh0 = ops.linear_dgrad(dz1, params[2])
