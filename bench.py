@@ -157,8 +157,9 @@ class KernelTimer:
             out = orig_wgrad(dy, x, dW, *a, **kw)
             e.record()
             xin = x if x is not None else kw["x16"]          # bf16 data path: the layer input was saved in bf16 only
-            timer.records.setdefault(("gemm_f32", "TN"), []).append((s, e, 2.0 * dy.shape[0] * dy.shape[1] * xin.shape[1]))
-            timer.shapes.setdefault(("TN", dy.shape[1], xin.shape[1], dy.shape[0]), []).append((s, e))
+            dyin = dy if dy is not None else kw["dy16"]      # ... and so was this gradient
+            timer.records.setdefault(("gemm_f32", "TN"), []).append((s, e, 2.0 * dyin.shape[0] * dyin.shape[1] * xin.shape[1]))
+            timer.shapes.setdefault(("TN", dyin.shape[1], xin.shape[1], dyin.shape[0]), []).append((s, e))
             return out
 
         ops.linear_wgrad = linear_wgrad

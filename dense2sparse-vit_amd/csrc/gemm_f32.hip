@@ -928,8 +928,9 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
                      int remap_rows_per_img, int remap_skip, int accumulate, void* workspace, size_t workspace_bytes,
                      hipStream_t stream, float* colsum_out, int mode, const void* a16 = nullptr, void* c16 = nullptr, const void* b16 = nullptr) {
     // layout 2 (weight gradient): a16 is the bf16 form of the SECOND operand (the layer input x); B may then be NULL
-    if (b16 && (mode != 2 || layout == 2 || K % 32 != 0 || !aligned16(b16))) return D2S_ERR_ARG;
-    if ((!A && !(a16 && layout != 2)) || (!B && !(a16 && layout == 2) && !b16) || (!C && !c16) || M <= 0 || N <= 0 || K <= 0 || layout < 0 || layout > 2 || mode < 0 || mode > 2) return D2S_ERR_ARG;
+    // layout 2: b16 is the bf16 form of the FIRST operand (dy); A may then be NULL
+    if (b16 && (mode != 2 || (layout != 2 && (K % 32 != 0 || !aligned16(b16))) || (layout == 2 && (!bf16_wgrad(mode) || (reinterpret_cast<uintptr_t>(b16) & 7))))) return D2S_ERR_ARG;
+    if ((!A && !(a16 && layout != 2) && !(b16 && layout == 2)) || (!B && !(a16 && layout == 2) && !(b16 && layout != 2)) || (!C && !c16) || M <= 0 || N <= 0 || K <= 0 || layout < 0 || layout > 2 || mode < 0 || mode > 2) return D2S_ERR_ARG;
     if ((a16 || c16) && (mode != 2 || (layout != 2 && accumulate) || remap_rows_per_img > 0)) return D2S_ERR_ARG;   // bf16 operands / copies exist in bf16 mode only
     if (layout == 2 && (c16 || (a16 && !bf16_wgrad(mode)))) return D2S_ERR_ARG;
     if (layout == 2 && a16) {
@@ -1084,12 +1085,13 @@ int d2s_linear_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, f
                      accumulate, workspace, workspace_bytes, stream, db, mode);
 }
 // The same in mode 2 with the layer input given in bf16 only (x_bf16 [tokens][n_in], row stride ldx elements): what the bf16 data path
-// saved for the backward instead of the fp32 activation.  dy stays fp32 (its exact column sums are the bias gradient).
-int d2s_linear_wgrad_f32_bf16x(const float* dy, long lddy, const void* x_bf16, long ldx, float* dW, long lddw, float* db, int tokens,
-                               int n_out, int n_in, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    if (!x_bf16) return D2S_ERR_ARG;
-    return gemm_impl(2, dy, lddy, nullptr, ldx, dW, lddw, n_out, n_in, tokens, EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0,
-                     accumulate, workspace, workspace_bytes, stream, db, 2, x_bf16, nullptr);
+// saved for the backward instead of the fp32 activation.  dy is fp32 (its exact column sums are the bias gradient) or, when the kernel that
+// produced it wrote bf16 only, dy_bf16 [tokens][n_out] (dy may be NULL; the bias gradient is then the sum of the bf16 values).
+int d2s_linear_wgrad_f32_bf16x(const float* dy, const void* dy_bf16, long lddy, const void* x_bf16, long ldx, float* dW, long lddw, float* db,
+                               int tokens, int n_out, int n_in, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!x_bf16 || (!dy && !dy_bf16)) return D2S_ERR_ARG;
+    return gemm_impl(2, dy_bf16 ? nullptr : dy, lddy, nullptr, ldx, dW, lddw, n_out, n_in, tokens, EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0,
+                     accumulate, workspace, workspace_bytes, stream, db, 2, x_bf16, nullptr, dy_bf16);
 }
 
 // dst[C][R] = src[R][C]^T (dense row-major): the k-contiguous copy of a Linear weight for the input-gradient GEMM.

@@ -704,7 +704,12 @@ int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_
     __bf16* Ap = static_cast<__bf16*>(pieces_ws);
     __bf16* Bp = reinterpret_cast<__bf16*>(static_cast<unsigned char*>(pieces_ws) + align256((size_t)split * p.M * Kp * sizeof(__bf16)));
     dim3 block(256);
-    hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.M + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA, colsum_part);
+    if (p.b16)      // bf16 data path: dy handed over in bf16 (the gradient a GEMM epilogue / attention backward wrote in that form only); its
+                    // column sums - the bias gradient - are then sums of the bf16 values, as under torch.autocast
+        hipLaunchKernelGGL((split_cols_kernel<1, __bf16>), dim3((p.M + 63) / 64, (Kp + 63) / 64), block, 0, stream, static_cast<const __bf16*>(p.b16), p.lda, Ap,
+                           p.M, p.K, Kp, (int)((p.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.b16) & 7) == 0)), colsum_part);
+    else
+        hipLaunchKernelGGL(split_cols_kernel<1>, dim3((p.M + 63) / 64, (Kp + 63) / 64), block, 0, stream, p.A, p.lda, Ap, p.M, p.K, Kp, p.vecA, colsum_part);
     if (p.a16)      // weight gradient on the bf16 data path: the layer input x ([tokens][n_in]) was saved in bf16 only
         hipLaunchKernelGGL((split_cols_kernel<1, __bf16>), dim3((p.N + 63) / 64, (Kp + 63) / 64), block, 0, stream, static_cast<const __bf16*>(p.a16), p.ldb, Bp,
                            p.N, p.K, Kp, (int)((p.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.a16) & 7) == 0)), static_cast<float*>(nullptr));

@@ -263,10 +263,13 @@ class BlockFn(torch.autograd.Function):
         if gyh is not None:
             gyh = gyh.view(M, D)
         dzh = ops.bf16_buffer(M, z.shape[1], dev) if io else None
-        dz = ops.linear_dgrad(gy, fc2w, epi=ops.EPI_MUL_GELU_GRAD, aux=z, a16=gyh, c16=dzh)
-        del gyh
         l2x, l216 = xarg(ln2)
-        grads[9], grads[10] = ops.linear_param_grads(dz, l2x, fc1w, fc1b, wants[9], wants[10], x16=l216)
+        # dz = (gy fc2w) * gelu'(z) feeds two bf16 GEMMs and nothing else: on the bf16 data path only its bf16 form is written (fc1's bias
+        # gradient is then the fp32 sum of those bf16 values, as under torch.autocast)
+        dz_bf16_only = dzh is not None and l216 is not None and wants[9]
+        dz = ops.linear_dgrad(gy, fc2w, epi=ops.EPI_MUL_GELU_GRAD, aux=z, a16=gyh, c16=dzh, want_f32=not dz_bf16_only)
+        del gyh
+        grads[9], grads[10] = ops.linear_param_grads(dz, l2x, fc1w, fc1b, wants[9], wants[10], x16=l216, dy16=dzh if dz_bf16_only else None)
         dln2 = ops.linear_dgrad(dz, fc1w, a16=dzh)
         del dzh
         g1 = torch.empty((M, D), dtype=torch.float32, device=dev)

@@ -22,7 +22,7 @@ _SIGS = {
     "d2s_convert_bf16": (I, [P, P, L]),
     "d2s_linear_wgrad_workspace_bytes": (Z, [I, I, I, I]),
     "d2s_linear_wgrad_f32": (I, [P, L, P, L, P, L, P, I, I, I, I, I, P, Z]),
-    "d2s_linear_wgrad_f32_bf16x": (I, [P, L, P, L, P, L, P, I, I, I, I, P, Z]),
+    "d2s_linear_wgrad_f32_bf16x": (I, [P, P, L, P, L, P, L, P, I, I, I, I, P, Z]),
     "d2s_batchnorm_workspace_bytes": (Z, [L, I]),
     "d2s_batchnorm_fwd": (I, [P, P, P, P, P, P, P, P, L, I, F, F, I, P, Z]),
     "d2s_batchnorm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, L, I, P, Z]),

@@ -253,13 +253,16 @@ class TransposedArena:
             _WT[w.data_ptr()] = (weights_epoch, w._version, tuple(w.shape), wt)
 
 
-def linear_dgrad(dy, W, epi=EPI_NONE, aux=None, out=None, a16=None, c16=None):
-    """dx[M,K] = epi(dy[M,N] @ W[N,K]).  bf16 mode only: a16 = bf16 copy of dy, c16 = bf16 [M, K] buffer receiving a copy of dx."""
-    _f32(dy), _f32(W)
-    M, N = dy.shape
+def linear_dgrad(dy, W, epi=EPI_NONE, aux=None, out=None, a16=None, c16=None, want_f32=True):
+    """dx[M,K] = epi(dy[M,N] @ W[N,K]).  bf16 mode only: a16 = bf16 copy of dy (dy may then be None), c16 = bf16 [M, K] buffer receiving a
+    copy of dx; want_f32=False (needs c16) skips the fp32 result and returns None."""
+    _f32(W)
+    if dy is not None:
+        _f32(dy)
+    M, N = (dy if dy is not None else a16).shape
     K = W.shape[1]
-    if out is None:
-        out = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    if out is None and want_f32:
+        out = torch.empty((M, K), dtype=torch.float32, device=W.device)
     if get_gemm_mode() == GEMM_BF16:
         wt16 = bf16_weight(W, transposed=True)      # [K][N] = W^T in bf16: the k-contiguous B operand of dx = dy W
         if a16 is not None or c16 is not None or wt16 is not None:
@@ -269,20 +272,25 @@ def linear_dgrad(dy, W, epi=EPI_NONE, aux=None, out=None, a16=None, c16=None):
     return gemm(NN, dy, N, W, K, out, K, M, K, N, epi, None, aux, K if aux is not None else 0)
 
 
-def linear_wgrad(dy, x, dW, accumulate=False, db=None, x16=None):
+def linear_wgrad(dy, x, dW, accumulate=False, db=None, x16=None, dy16=None):
     """dW[N,K] (+)= dy[M,N]^T @ x[M,K]; with db also db[N] (+)= dy.sum(0), folded into the same pass over dy.
-    bf16 mode: x16 = the layer input in bf16 (x may then be None - the bf16 data path saves only that form)."""
-    _f32(dy), _f32(dW)
-    M, N = dy.shape
+    bf16 mode: x16 = the layer input in bf16 (x may then be None - the bf16 data path saves only that form); dy16 = the gradient in bf16
+    where its producer wrote only that (dy may then be None; needs x16)."""
+    _f32(dW)
+    if dy is not None:
+        _f32(dy)
+    M, N = (dy if dy is not None else dy16).shape
     K = (x if x is not None else x16).shape[1]
     mode = get_gemm_mode()
     need = lib.query("d2s_linear_wgrad_workspace_bytes", M, N, K, mode)
     ws = workspace(need, dW.device) if need else None
     if x16 is not None:
         assert mode == GEMM_BF16 and x16.dtype == torch.bfloat16 and x16.is_contiguous() and tuple(x16.shape) == (M, K)
-        lib.call("d2s_linear_wgrad_f32_bf16x", lib.ptr(dy), N, lib.ptr(x16), K, lib.ptr(dW), K, lib.ptr(db), M, N, K, int(accumulate),
-                 lib.ptr(ws), ws.numel() if ws is not None else 0)
+        assert dy16 is None or (dy16.dtype == torch.bfloat16 and dy16.is_contiguous() and tuple(dy16.shape) == (M, N))
+        lib.call("d2s_linear_wgrad_f32_bf16x", lib.ptr(dy), lib.ptr(dy16), N, lib.ptr(x16), K, lib.ptr(dW), K, lib.ptr(db), M, N, K,
+                 int(accumulate), lib.ptr(ws), ws.numel() if ws is not None else 0)
         return dW
+    assert dy16 is None, "a bf16 gradient needs the bf16 layer input as well"
     _f32(x)
     lib.call("d2s_linear_wgrad_f32", lib.ptr(dy), N, lib.ptr(x), K, lib.ptr(dW), K, lib.ptr(db), M, N, K, int(accumulate), mode,
              lib.ptr(ws), ws.numel() if ws is not None else 0)
@@ -328,16 +336,19 @@ def join_weight_grads():
     _WGRAD["used"] = False
 
 
-def linear_param_grads(dy, x, W, b, want_w=True, want_b=True, accumulate=False, x16=None):
-    """(dW, db) of a Linear into fresh arena-backed buffers: one fused pass when both are wanted.  x16: see linear_wgrad."""
+def linear_param_grads(dy, x, W, b, want_w=True, want_b=True, accumulate=False, x16=None, dy16=None):
+    """(dW, db) of a Linear into fresh arena-backed buffers: one fused pass when both are wanted.  x16 / dy16: see linear_wgrad."""
     dW = grad_buffer(W) if want_w else None
     db = grad_buffer(b) if (want_b and b is not None) else None
     if dW is None and db is None:
         return dW, db
-    side = _WGRAD["stream"] if (_WGRAD["on"] and dy.is_cuda) else None
+    src = dy if dy is not None else dy16
+    if dW is None and dy is None:
+        dy = dy16.float()            # bias gradient alone from a bf16-only gradient (not on the model's path: weights and biases train together)
+    side = _WGRAD["stream"] if (_WGRAD["on"] and src.is_cuda) else None
     if side is None:
         if dW is not None:
-            linear_wgrad(dy, x, dW, accumulate=accumulate, db=db, x16=x16)
+            linear_wgrad(dy, x, dW, accumulate=accumulate, db=db, x16=x16, dy16=dy16)
         else:
             colsum(dy, db, accumulate=accumulate)
         return dW, db
@@ -345,10 +356,10 @@ def linear_param_grads(dy, x, W, b, want_w=True, want_b=True, accumulate=False, 
     side.wait_stream(main)                       # dy (and x) were produced on the main stream
     with torch.cuda.stream(side):
         if dW is not None:
-            linear_wgrad(dy, x, dW, accumulate=accumulate, db=db, x16=x16)
+            linear_wgrad(dy, x, dW, accumulate=accumulate, db=db, x16=x16, dy16=dy16)
         else:
             colsum(dy, db, accumulate=accumulate)
-    for t in (dy, x, x16, dW, db):                    # autograd may free these on the main stream while the side stream still reads / writes them
+    for t in (dy, dy16, x, x16, dW, db):                    # autograd may free these on the main stream while the side stream still reads / writes them
         if t is not None:
             t.record_stream(side)
     _WGRAD["used"] = True

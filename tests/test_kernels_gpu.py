@@ -556,6 +556,13 @@ def test_linear_wgrad_bf16_input(ops, tokens, n_out, n_in):
         dW2, db2 = torch.empty(n_out, n_in, device=_dev()), torch.empty(n_out, device=_dev())
         ops.linear_wgrad(dy, None, dW2, db=db2, x16=x.bfloat16())
         assert torch.equal(dW1, dW2) and torch.equal(db1, db2)
+        # the gradient in bf16 as well: same weight gradient (the same rounded values are multiplied); the bias gradient is the sum of the
+        # bf16 values, 2^-9 relative per element away from the exact column sum
+        dW3, db3 = torch.empty(n_out, n_in, device=_dev()), torch.empty(n_out, device=_dev())
+        ops.linear_wgrad(None, None, dW3, db=db3, x16=x.bfloat16(), dy16=dy.bfloat16())
+        assert torch.equal(dW3, dW1)
+        ref_b = dy.bfloat16().double().sum(0)
+        assert (db3.double() - ref_b).abs().max() <= 1e-5 * math.sqrt(tokens) * 10
     finally:
         ops.set_gemm_mode(ops.GEMM_EXACT)
 
