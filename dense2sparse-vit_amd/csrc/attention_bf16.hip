@@ -255,7 +255,7 @@ __device__ __forceinline__ void store_t(const f32x16 (&acc)[2], float* __restric
             f32x4 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = acc[dt][4 * g + j] * mul;
-            *reinterpret_cast<f32x4*>(p + off + 32 * dt + 8 * g + 4 * half) = v;
+            if (p) *reinterpret_cast<f32x4*>(p + off + 32 * dt + 8 * g + 4 * half) = v;
             if (p16) {
                 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
                 bf16x4_t hv;
@@ -403,7 +403,7 @@ extern "C" int d2s_attn_delta(const float* out, const float* dout, float* delta,
 template <typename QT>
 static int attn_bwd_bf16_impl(const QT* qkv, const float* out, const float* dout, const float* lse, float* dqkv, __bf16* dqkv16,
                               float* delta_ws, int B, int n, int H, float scale, hipStream_t stream) {
-    if (!qkv || !out || !dout || !lse || !dqkv || !delta_ws || B <= 0 || n <= 0 || H <= 0) return D2S_ERR_ARG;
+    if (!qkv || !out || !dout || !lse || (!dqkv && !dqkv16) || !delta_ws || B <= 0 || n <= 0 || H <= 0) return D2S_ERR_ARG;
     const int rc = d2s_attn_delta(out, dout, delta_ws, B, n, H, stream);
     if (rc != D2S_OK) return rc;
     dim3 grid((n + 127) / 128, B * H), block(256);
@@ -445,7 +445,7 @@ int d2s_attn_bwd_bf16(const float* qkv, const float* out, const float* dout, con
     return attn_bwd_bf16_impl<float>(qkv, out, dout, lse, dqkv, nullptr, delta_ws, B, n, H, scale, stream);
 }
 // ... on the bf16 data path: qkv optionally in bf16 (as in the forward), and a bf16 copy of dqkv (same [B,n,3,H,64] layout): the a_bf16
-// of the qkv Linear's input-gradient GEMM
+// of the qkv Linear's input-gradient GEMM and the dy_bf16 of its weight gradient; dqkv may be NULL when only that form is consumed
 int d2s_attn_bwd_bf16_bf16out(const void* qkv, int qkv_is_bf16, const float* out, const float* dout, const float* lse, float* dqkv,
                               void* dqkv_bf16, float* delta_ws, int B, int n, int H, float scale, hipStream_t stream) {
     if (!dqkv_bf16) return D2S_ERR_ARG;

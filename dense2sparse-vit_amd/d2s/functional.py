@@ -283,14 +283,16 @@ class BlockFn(torch.autograd.Function):
         dao = ops.linear_dgrad(g1, projw, a16=g1h)
         del g1h
         dqkvh = None
+        l1x, l116 = xarg(ln1)
+        dqkv_bf16_only = False
         if policy is None:
             if io_attn:
                 dqkvh = torch.empty(qkv.shape, dtype=torch.bfloat16, device=dev)
-            dqkv = ops.attn_bwd(qkv, ao, dao, lse, B, n, heads, scale, dqkv16=dqkvh)
+                dqkv_bf16_only = l116 is not None and wants[3]      # both consumers (weight gradient, input gradient) read the bf16 form
+            dqkv = ops.attn_bwd(qkv, ao, dao, lse, B, n, heads, scale, dqkv16=dqkvh, want_f32=not dqkv_bf16_only)
         else:
             dqkv = ops.attn_policy_bwd(qkv, policy, ao, dao, lse, cinv, B, n, heads, scale)
-        l1x, l116 = xarg(ln1)
-        grads[3], grads[4] = ops.linear_param_grads(dqkv, l1x, qkvw, qkvb, wants[3], wants[4], x16=l116)
+        grads[3], grads[4] = ops.linear_param_grads(dqkv, l1x, qkvw, qkvb, wants[3], wants[4], x16=l116, dy16=dqkvh if dqkv_bf16_only else None)
         gx = None
         if wants[0] or wants[1] or wants[2]:
             dln1 = ops.linear_dgrad(dqkv, qkvw, a16=dqkvh)

@@ -572,9 +572,10 @@ def attn_fwd_bf16io(qkv, B, n, H, scale, want_cls=True, want_f32=True):
     return out, lse, cls_row, out16
 
 
-def attn_bwd(qkv, out, dout, lse, B, n, H, scale, dqkv16=None):
-    """dqkv16 (bf16 mode with the bf16 attention kernels): bf16 buffer shaped like qkv that receives a copy of dqkv."""
-    dqkv = torch.empty(qkv.shape, dtype=torch.float32, device=qkv.device)
+def attn_bwd(qkv, out, dout, lse, B, n, H, scale, dqkv16=None, want_f32=True):
+    """dqkv16 (bf16 mode with the bf16 attention kernels): bf16 buffer shaped like qkv that receives a copy of dqkv; want_f32=False
+    (needs dqkv16): only that form is written and None is returned."""
+    dqkv = torch.empty(qkv.shape, dtype=torch.float32, device=qkv.device) if (want_f32 or dqkv16 is None) else None
     delta = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device)
     bf16 = get_gemm_mode() == GEMM_BF16 and _BF16_ATTENTION
     if dqkv16 is not None:

@@ -132,7 +132,7 @@ int d2s_attn_delta(const float* out, const float* dout, float* delta, int B, int
 int d2s_attn_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta_ws,
                      int B, int n, int H, float scale, d2s_stream_t stream);
 /* ... on the bf16 data path: qkv optionally in bf16 (as in the forward) and a bf16 copy of dqkv in the same [B,n,3,H,64] layout (the
- * a_bf16 of the qkv Linear's input-gradient GEMM) */
+ * a_bf16 of the qkv Linear's input-gradient GEMM and the dy_bf16 of its weight gradient; dqkv may be NULL when only that form is used) */
 int d2s_attn_bwd_bf16_bf16out(const void* qkv, int qkv_is_bf16, const float* out, const float* dout, const float* lse, float* dqkv,
                               void* dqkv_bf16, float* delta_ws, int B, int n, int H, float scale, d2s_stream_t stream);
 

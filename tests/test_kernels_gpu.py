@@ -491,6 +491,8 @@ def test_attn_bwd_bf16out(ops):
         d16b = torch.empty_like(d16)
         d3 = ops.attn_bwd(qkv.bfloat16(), out, dout, lse, B, n, H, 0.125, dqkv16=d16b)      # bf16 qkv in: identical gradients
         assert torch.equal(d3, d1) and torch.equal(d16b, d16)
+        d16c = torch.empty_like(d16)
+        assert ops.attn_bwd(qkv, out, dout, lse, B, n, H, 0.125, dqkv16=d16c, want_f32=False) is None and torch.equal(d16c, d16)
     finally:
         ops.set_gemm_mode(0)
 
