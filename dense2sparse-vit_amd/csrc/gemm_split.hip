@@ -16,6 +16,9 @@
 //   2. matrix kernel: tile 128x128x32, 4 waves 2x2, each 64x64 = 2x2 tiles of v_mfma_f32_32x32x16_bf16; pieces are loaded with
 //      16-byte loads straight into an LDS image [piece][row][40 bf16] (80-byte pitch: conflict-free ds_read_b128 fragments),
 //      next K-slab prefetched to registers during the MFMAs, no VALU work in the loop; 2 workgroups per CU.
+// With one piece (bf16 mode) and a large shape, stage 2 is gemm_bf16_dma_kernel instead (further down: 256x256 / 256x128 tiles fed by
+// LDS-DMA), and stage 1 disappears for every operand whose producer already wrote it in bf16 (d2s_gemm_f32_bf16io: a_bf16 from
+// LayerNorm / attention / a GEMM epilogue, b_bf16 from the per-step weight conversion, c_bf16 for the next GEMM).
 #include "gemm_common.h"
 #include <cstdlib>
 
