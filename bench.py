@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--serial", action="store_true",
                     help="issue every kernel on one stream also in the timed region (no teacher / weight-gradient stream overlap): the form in which "
                          "per-kernel durations are meaningful - used for the rocprofv3 kernel-stats profile that has to agree with roofline.avg_launch_us")
+    ap.add_argument("--batch-override", type=int, default=0,
+                    help="per-GPU batch that also overrides a --config preset's batch (extra data points; config.workload names the batch that ran)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented pass (no per-kernel figures in the line)")
     ap.add_argument("--time-kernels-in-region", action="store_true",
@@ -80,6 +82,8 @@ def parse():
         a.arch, a.keeps, a.batch = "t2t_vit_14", [0.5], 64
     elif a.config == "c5":
         a.arch, a.img, a.keeps, a.batch, a.gemm_mode = "deit_base", 384, [0.3], 64, "bf16"
+    if a.batch_override > 0:
+        a.batch = a.batch_override
     if a.config != "headline":
         a.no_cpu_baseline = True
         a.keep = a.keeps[0]
