@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: training images/s of the dense-to-sparse ViT step on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`:
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or - when WORLD_SIZE is not set - this process starts them itself
+(launch_ranks: N fresh children through torch.distributed.run on 127.0.0.1, before anything here touches the GPU; the reference spawns
+its workers the same way, mask_predictor.py:160-162 `mp.spawn`, ddp_training.py:4-8), forwards rank 0's JSON line and exits non-zero if
+any child did.  A line is only printed when the process group's world size equals --gpus.
 
 A "step" is exactly train.py:40-57 of the reference: frozen teacher forward, student forward (token scoring, top-k
 selection, kept-token gather, pruned blocks), MaskLoss + BackboneLoss, backward, AdamW update - on one synthetic batch
@@ -68,7 +74,12 @@ def parse():
                          "per-kernel durations are meaningful - used for the rocprofv3 kernel-stats profile that has to agree with roofline.avg_launch_us")
     ap.add_argument("--batch-override", type=int, default=0,
                     help="per-GPU batch that also overrides a --config preset's batch (extra data points; config.workload names the batch that ran)")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="capture the step into a hipGraph and replay it (d2s.engine.TrainStep graph mode): auto = small per-rank batches only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rehearse the N-rank launch path without a GPU: the ranks rendezvous over gloo, all-reduce their rank ids and rank 0 "
+                         "prints a line with n_gpus / ranks read back from the process group (tests/test_bench_launcher.py)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented pass (no per-kernel figures in the line)")
     ap.add_argument("--time-kernels-in-region", action="store_true",
                     help="put the per-kernel HIP events inside the timed region itself (they cost ~5 %% of the step: ~900 event records)")
@@ -330,8 +341,72 @@ def log(msg):
 _T0 = time.perf_counter()
 
 
+def launch_ranks(args):
+    """--gpus N > 1 without a launcher around us: start N fresh rank processes (one per GPU, RCCL rendezvous on 127.0.0.1) and relay
+    rank 0's JSON line.  Runs BEFORE this process has made any GPU call (no torch.cuda.*, no lib.load()); the ranks are children,
+    never an exec of this process.  Returns the exit code for the parent: the children's if non-zero, 1 if no line came back."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # this pool's driver only supports dmabuf IPC (RCCL needs it across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    log(f"starting {args.gpus} ranks: {' '.join(cmd)}")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = []
+    for ln in proc.stdout:
+        if ln.lstrip().startswith("{"):
+            lines.append(ln.strip())
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc != 0:
+        log(f"rank processes exited with code {rc}")
+        return rc
+    if len(lines) != 1:
+        log(f"expected ONE JSON line from rank 0, got {len(lines)}")
+        return 1
+    got = json.loads(lines[0]).get("n_gpus")
+    if got != args.gpus:
+        log(f"rank 0 reports n_gpus = {got}, asked for {args.gpus}: not printing")
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
+def launch_check(args):
+    """One rank of the launch rehearsal (no GPU): gloo rendezvous from the launcher's environment, every rank contributes its id, rank 0
+    prints what the process group says about itself."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29555")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ids = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(ids, torch.tensor([rank], dtype=torch.int64))
+    total = torch.tensor([float(rank + 1)])
+    dist.all_reduce(total)
+    n = dist.get_world_size()
+    ok = n == args.gpus and int(total.item()) == n * (n + 1) // 2
+    dist.barrier()
+    if rank == 0 and ok:
+        print(json.dumps({"launch_check": True, "n_gpus": n, "ranks": [int(t.item()) for t in ids], "backend": "gloo",
+                          "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}), flush=True)
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(f"launch check failed: world size {n}, --gpus {args.gpus}")
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
+    if args.launch_check:
+        return launch_check(args)
     # RCCL prints a version banner on STDOUT at communicator creation; the contract is ONE JSON line there, so everything
     # before the final print is routed to stderr at the file-descriptor level.
     sys.stdout.flush()
@@ -342,6 +417,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_dist = os.environ.get("D2S_FORCE_DIST") == "1"     # rehearse the RCCL path with a single rank
     distributed = world > 1 or force_dist
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: refusing to report a line for a different rank count")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the d2s path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -361,7 +438,9 @@ def main():
     student, teacher = build(device, args.keep, arch=args.arch, locs=args.locs, keeps=args.keeps, img=args.img, init_n=args.init_n)
     targs = types.SimpleNamespace(keep_ratios=list(args.keeps), mask_loss_type="kl_div", mixup=0.0, patch_score_threshold=None, step=0)
     ts = TrainStep(student, teacher, targs, lr=5e-4, min_lr=1e-5, weight_decay=0.05, epochs=25, warmup_steps=0,
-                   distributed=distributed)
+                   distributed=distributed, graph={"auto": None, "on": True, "off": False}[args.graph])
+    if ts._use_graph(torch.empty((args.batch, 1), device=device)) and args.warmup < ts.GRAPH_WARM_STEPS + 1:
+        args.warmup = ts.GRAPH_WARM_STEPS + 1        # the capture itself must not fall into the timed region
     if args.serial:
         ts._teacher_stream = None
         ops._WGRAD_ENABLED = False
@@ -389,15 +468,19 @@ def main():
     timer.enabled = in_region
     if distributed:
         ts.reducer.timing = True
+    host_s = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         info = ts(images, labels)
+        host_s += time.perf_counter() - h0       # time the host spends issuing one step (no synchronisation inside)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    captured = ts.last_step_captured
     loss = float(info["loss"])
     log(f"timed region done: {args.steps} steps in {elapsed:.3f} s, loss {loss:.5f}")
     instr_elapsed = elapsed if in_region else None
@@ -407,6 +490,7 @@ def main():
         # in series with the student's (the timed region above overlaps them on two streams)
         two_streams = getattr(ts, "_teacher_stream", None)
         ts._teacher_stream = None
+        graph_mode, ts.graph = ts.graph, False      # per-kernel events need the kernels issued one by one
         wgrad_async, ops._WGRAD_ENABLED = ops._WGRAD_ENABLED, False      # ... and the weight gradients on the main stream
         t1 = time.perf_counter()
         for _ in range(args.steps):
@@ -418,6 +502,7 @@ def main():
         instr_elapsed = time.perf_counter() - t1
         timer.enabled = False
         ts._teacher_stream = two_streams
+        ts.graph = graph_mode
         ops._WGRAD_ENABLED = wgrad_async
         log(f"instrumented pass done: {args.steps} steps in {instr_elapsed:.3f} s")
 
@@ -426,15 +511,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    if distributed and dist.get_world_size() != args.gpus:
+        raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
     if rank == 0:
-        n_gpus = world
+        n_gpus = dist.get_world_size() if distributed else 1       # read back from the process group, not from the flag
         imgs = args.batch * n_gpus * args.steps
         line = {
             "metric": "training images/s, DeiT-S 224 keep_ratio=0.5 (dense-to-sparse ViT train step, teacher fwd + student fwd/bwd + AdamW)"
                       if args.config == "headline" and args.keep == 0.5 else
                       f"training images/s, BASELINE config {args.config} (NOT the headline metric): {args.arch} {args.img}^2 keep {args.keeps}",
             "value": round(imgs / elapsed, 2), "unit": "images/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
+            "host_enqueue_ms_per_step": round(1000.0 * host_s / args.steps, 3),
+            "step_issue": "hipGraph replay (forward + losses + backward captured once; gradient exchange, AdamW launch and loss running means issued per step)"
+                          if captured else "eager (one C-ABI call per kernel from the autograd Functions)",
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"exact": "f32", "split": "f32 (bf16x3-split MFMA, fp32-class accuracy)", "bf16": "bf16 GEMM operands, f32 accumulate/elsewhere"}[args.gemm_mode], "data": "synthetic (N(0,1) images, uniform labels, random-init weights)",
             "config": {"workload": (f"DeiT-Small 224x224 patch16, 1-stage prune keep_ratio={args.keep} @ block 3 (196->{int(196 * args.keep)} tokens), "
                                     f"large LN predictor, kl_div mask loss, per-GPU batch {args.batch}") if args.config in ("headline", "c2") else

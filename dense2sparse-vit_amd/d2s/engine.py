@@ -118,7 +118,11 @@ class FusedAdamW:
             desc["lr"][c0:c1] = self.group_lr[g]
             desc["wd"][c0:c1] = self.group_wd[g]
             desc["active"][c0:c1] = 1
-        self._desc = torch.from_numpy(desc.view(np.uint8).copy()).to(a.params.device)
+        new = torch.from_numpy(desc.view(np.uint8).copy())
+        if self._desc is None:
+            self._desc = new.to(a.params.device)
+        else:                           # in place: a captured step (TrainStep graph mode) keeps reading this buffer
+            self._desc.copy_(new, non_blocking=False)
         self._dirty = False
 
     def mark_dirty(self):
@@ -199,10 +203,22 @@ class GradReducer:
     all-reduced with RCCL on a side stream as soon as autograd has finished the layers that own them (reverse layer
     order), so the exchange overlaps the remaining backward; joined before the optimiser step."""
 
-    def __init__(self, arena, group=None, bucket_mb=16.0):
+    def __init__(self, arena, group=None, bucket_mb=None, collective=None):
+        """bucket_mb (default: D2S_DDP_BUCKET_MB, else 16): smallest slice worth a collective of its own.
+        collective (default: D2S_DDP_COLLECTIVE, else "allreduce"): "allreduce" = one all_reduce per bucket; "rs_ag" = reduce_scatter
+        into this rank's 1/world shard of the bucket (in place) followed by an all_gather of the shards - the two halves of a direct
+        all-reduce over the fully connected xGMI mesh (SURVEY 8d sizes both forms); same sums, same result layout."""
+        import os
         self.arena, self.group = arena, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.stream = torch.cuda.Stream() if arena.params.is_cuda else None
+        if bucket_mb is None:
+            bucket_mb = float(os.environ.get("D2S_DDP_BUCKET_MB", "16"))
+        self.collective = collective or os.environ.get("D2S_DDP_COLLECTIVE", "allreduce")
+        if self.collective not in ("allreduce", "rs_ag"):
+            raise ValueError(f"collective {self.collective!r}: expected 'allreduce' or 'rs_ag'")
+        self.bucket_mb = bucket_mb
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self._hi = arena.total
         # arena ranges [lo, hi) whose gradients exist this epoch (ascending, merged); None = the whole arena.  requires_grad flips
@@ -210,8 +226,10 @@ class GradReducer:
         # optimised (utils.py:79-80), so their slices are not exchanged either (set_live_ranges, called from TrainStep.set_epoch)
         self.live = None
         self.force = False      # rehearsal: issue the collectives even with a single rank
+        self.paused = False
         self.timing = False     # bench: bracket every collective with events on the side stream
         self._events, self._exposed, self._bytes, self._launched = [], [], 0, False
+        self._n_collectives = 0
 
     def set_live_ranges(self, ranges):
         """ranges: iterable of (lo, hi) arena offsets holding live gradients; merged when they touch."""
@@ -238,11 +256,25 @@ class GradReducer:
                 if b > a:
                     self._reduce(a, b)
 
+    def _collective(self, buf, async_op):
+        """SUM of `buf` over the ranks, result in `buf` on every rank.  -> list of work handles (async_op) or []"""
+        n = buf.numel()
+        if self.collective == "rs_ag" and self.world > 1 and n % self.world == 0:
+            per = n // self.world
+            shard = buf[self.rank * per:(self.rank + 1) * per]          # in place: this rank's slot of the bucket
+            w1 = dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            w2 = dist.all_gather_into_tensor(buf, shard, group=self.group, async_op=async_op)
+            self._n_collectives += 2
+            return [w1, w2] if async_op else []
+        w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)     # also rs_ag's path for a slice the world does not divide
+        self._n_collectives += 1
+        return [w] if async_op else []
+
     def _reduce(self, lo, hi):
         buf = self.arena.grads[lo:hi]
         self._launched = True
         if self.stream is None:          # CPU tensors (gloo rehearsal): blocking
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            self._collective(buf, False)
             return
         self.stream.wait_stream(torch.cuda.current_stream())
         wg = ops.weight_grad_stream()
@@ -252,14 +284,17 @@ class GradReducer:
             if self.timing:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()   # stream-level wait: the side
-            if self.timing:                                                                        # stream follows RCCL's stream
+            for w in self._collective(buf, True):
+                w.wait()                 # stream-level wait: the side stream follows RCCL's stream
+            if self.timing:
                 e1.record()
                 self._events.append((e0, e1))
                 self._bytes += buf.numel() * 4
 
     def ready_from(self, lo):
         """Every gradient at arena offset >= lo is final."""
+        if self.paused:          # a step that is being captured into a hipGraph: no collective from inside; finish() sends everything
+            return
         if self._pending(lo) >= self.bucket_elems:
             self._launch(lo)
 
@@ -292,11 +327,12 @@ class GradReducer:
         t_ms = sum(a.elapsed_time(b) for a, b in self._events)
         exposed = sum(max(0.0, a.elapsed_time(b)) for a, b in self._exposed)
         n = max(self.world, 1)
-        out = {"allreduce_bytes_per_step": self._bytes / steps, "collectives_per_step": len(self._events) / steps,
+        out = {"allreduce_bytes_per_step": self._bytes / steps, "buckets_per_step": len(self._events) / steps,
+               "collectives_per_step": self._n_collectives / steps, "collective": self.collective, "bucket_mb": self.bucket_mb,
                "allreduce_ms_per_step": round(t_ms / steps, 3), "exposed_ms_per_step": round(exposed / steps, 3),
                "bus_GBps": round(2.0 * (n - 1) / n * self._bytes / (t_ms * 1e-3) / 1e9, 1) if t_ms > 0 else None,
                "backend": "nccl (RCCL)", "world": n}
-        self._events, self._exposed, self._bytes = [], [], 0
+        self._events, self._exposed, self._bytes, self._n_collectives = [], [], 0, 0
         return out
 
 
@@ -304,8 +340,11 @@ class TrainStep:
     """One optimiser step as train.py:40-57 defines it: teacher forward (no grad), student forward, MaskLoss +
     BackboneLoss, warm-up switch (train.py:50-53), zero_grad / backward / step."""
 
+    GRAPH_WARM_STEPS = 2        # eager steps of a given shape before it is captured (lazy one-time work happens there)
+
     def __init__(self, student, teacher, args, lr=5e-4, min_lr=1e-5, weight_decay=0.05, epochs=25, warmup_steps=0,
-                 distributed=False, bucket_mb=16.0):
+                 distributed=False, bucket_mb=None, collective=None, graph=None):
+        """graph: capture the step into a hipGraph and replay it (None: D2S_STEP_GRAPH = 0 | 1 | auto, default auto; see _use_graph)."""
         from losses import MaskLoss, BackboneLoss
         self.student, self.teacher, self.args = student, teacher, args
         self.teacher.eval()
@@ -319,7 +358,7 @@ class TrainStep:
         self.backbone_loss_fn = BackboneLoss(args)
         self.metrics = {}
         self.lr, self.min_lr, self.epochs, self.warmup_steps = lr, min_lr, epochs, warmup_steps
-        self.reducer = GradReducer(self.arena, bucket_mb=bucket_mb) if distributed else None
+        self.reducer = GradReducer(self.arena, bucket_mb=bucket_mb, collective=collective) if distributed else None
         if self.reducer is not None:
             student.grad_ready_hook = lambda i: self.reducer.ready_from(self.block_offset[i])
         self.frozen = frozenset(n for n, p in student.named_parameters() if not p.requires_grad)
@@ -328,6 +367,13 @@ class TrainStep:
         # +2.6 % images/s, identical losses (profiles/r02_f_teacher_stream_ab.txt).  D2S_TEACHER_STREAM=0 serialises them.
         two = os.environ.get("D2S_TEACHER_STREAM", "1") == "1" and self.arena.params.is_cuda
         self._teacher_stream = torch.cuda.Stream() if two else None
+        if graph is None:
+            graph = {"0": False, "1": True}.get(os.environ.get("D2S_STEP_GRAPH", "auto"), None)
+        self.graph = graph                  # True | False | None (auto)
+        self.graph_auto_max_rows = int(os.environ.get("D2S_STEP_GRAPH_AUTO_ROWS", "16384"))
+        self._graphs = {}                   # key -> entry (see _graph_step)
+        self._capture_stream = None
+        self.last_step_captured = False     # diagnostic: did the last call replay a graph
         self.set_epoch(0)
 
     def set_epoch(self, epoch):
@@ -343,7 +389,7 @@ class TrainStep:
                 if p.requires_grad and g is not None and g != "early_exit")
         return out
 
-    def forward_losses(self, images, labels):
+    def forward_losses(self, images, labels, accumulate=True):
         if self._teacher_stream is not None:
             # The frozen teacher's forward and the student's forward are independent until the losses: the teacher runs on a second
             # HIP stream so that its kernels fill the CUs the student's kernels leave idle in their ramp-up / last residency round
@@ -367,22 +413,106 @@ class TrainStep:
                 with torch.no_grad():
                     logits_t, token_t, cls_attn = self.teacher(images)
                 logits_s, token_s, pred_logits, kept = self.student(images)
-        mask_loss = self.mask_loss_fn(pred_logits, cls_attn, kept, self.metrics)
-        backbone_loss = self.backbone_loss_fn(logits_s, token_s, logits_t, token_t, kept, labels, self.metrics)
+        mask_loss = self.mask_loss_fn(pred_logits, cls_attn, kept, self.metrics, accumulate=accumulate)
+        backbone_loss = self.backbone_loss_fn(logits_s, token_s, logits_t, token_t, kept, labels, self.metrics, accumulate=accumulate)
         loss = mask_loss if self.epoch < self.warmup_steps else backbone_loss + mask_loss     # train.py:50-53
         return loss, dict(mask_loss=mask_loss, backbone_loss=backbone_loss, kept=kept, logits_s=logits_s, token_s=token_s,
                           pred_logits=pred_logits, logits_t=logits_t, token_t=token_t, cls_attn=cls_attn)
 
     def __call__(self, images, labels):
         self.arena.check_alias()
-        self.opt.refresh_transposed_weights()
-        self.student.train()
-        loss, info = self.forward_losses(images, labels)
-        self.opt.zero_grad()
-        with ops.async_weight_grads():              # wgrad GEMMs trail the dgrad chain on a second stream; joined on exit
-            loss.backward()
-        self.arena.collect_grads()
+        if self._use_graph(images):
+            return self._graph_step(images, labels)
+        self.last_step_captured = False
+        loss, info = self._forward_backward(images, labels, accumulate=True)
         scale = self.reducer.finish() if self.reducer is not None else 1.0
         self.opt.step(grad_scale=scale)
         info["loss"] = loss.detach()
         return info
+
+    def _forward_backward(self, images, labels, accumulate):
+        self.opt.refresh_transposed_weights()
+        self.student.train()
+        loss, info = self.forward_losses(images, labels, accumulate=accumulate)
+        self.opt.zero_grad()
+        with ops.async_weight_grads():              # wgrad GEMMs trail the dgrad chain on a second stream; joined on exit
+            loss.backward()
+        self.arena.collect_grads()
+        return loss, info
+
+    # ---- the step as a hipGraph ----
+    # With a fixed keep count every tensor of the step has a static shape and nothing in it synchronises with the host, so the ~450
+    # C-ABI launches + autograd bookkeeping of a step (9.5 ms of Python at 32 images per GPU) can be recorded once
+    # and replayed with one call.  What is captured: W^T / bf16 weight refresh, teacher and student forward (their two streams become
+    # two branches of the graph), losses, backward (the weight-gradient stream is a third branch).  What stays outside: the gradient
+    # exchange (RCCL collectives are issued eagerly after the replay - one flush of the live gradient set instead of buckets that
+    # overlap backward), the fused AdamW launch (its per-chunk learning rates and step counters live in device buffers that are
+    # updated in place), and the host-side running means of the two loss modules.
+    def _use_graph(self, images):
+        if self.graph is False or not images.is_cuda:
+            return False
+        if getattr(self.student, "patch_score_threshold", None) is not None:
+            return False                         # dynamic keep ratio: not needed for the fixed-k path this serves; stays eager
+        if self.graph is True:
+            return True
+        # auto: small per-rank batches, where the host cannot issue launches as fast as the GPU retires them (C3 / C4 regime).  With
+        # a reducer the eager path's overlap of the exchange with backward is worth more than the launch time at large batches.
+        n_tok = getattr(getattr(self.student, "patch_embed", None), "num_patches", 196) + 1
+        return images.shape[0] * n_tok <= self.graph_auto_max_rows
+
+    def _graph_key(self, images, labels):
+        live = tuple(p.requires_grad for p in self.arena.params_list)
+        return (tuple(images.shape), images.dtype, tuple(labels.shape), labels.dtype, self.epoch < self.warmup_steps, hash(live),
+                ops.get_gemm_mode(), self._teacher_stream is not None, ops._WGRAD_ENABLED)
+
+    def drop_graphs(self):
+        self._graphs.clear()
+
+    def _graph_step(self, images, labels):
+        key = self._graph_key(images, labels)
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) >= 4:           # shapes come and go (a shorter last batch): keep the pool of captured steps small
+                self._graphs.pop(next(iter(self._graphs)))
+            ent = self._graphs[key] = {"seen": 0, "graph": None}
+        if ent["graph"] is None and ent["seen"] < self.GRAPH_WARM_STEPS:
+            ent["seen"] += 1
+            self.last_step_captured = False
+            loss, info = self._forward_backward(images, labels, accumulate=True)
+            scale = self.reducer.finish() if self.reducer is not None else 1.0
+            self.opt.step(grad_scale=scale)
+            info["loss"] = loss.detach()
+            return info
+        if ent["graph"] is None:
+            self._capture(ent, images, labels)
+        ent["images"].copy_(images, non_blocking=True)
+        ent["labels"].copy_(labels, non_blocking=True)
+        ent["graph"].replay()
+        self.last_step_captured = True
+        scale = self.reducer.finish() if self.reducer is not None else 1.0
+        self.opt.step(grad_scale=scale)
+        self.mask_loss_fn.accumulate(self.metrics, ent["mask_last"])
+        self.backbone_loss_fn.accumulate(self.metrics, ent["backbone_last"])
+        return ent["info"]          # static tensors: overwritten by the next replay of this graph
+
+    def _capture(self, ent, images, labels):
+        if self.opt._dirty:
+            self.opt._build_desc()               # host -> device copy: before the capture, not inside it
+        if self._capture_stream is None:
+            self._capture_stream = torch.cuda.Stream()
+        ent["images"], ent["labels"] = images.clone(), labels.clone()
+        g = torch.cuda.CUDAGraph()
+        if self.reducer is not None:
+            self.reducer.paused = True
+        torch.cuda.synchronize()
+        try:
+            with torch.cuda.graph(g, stream=self._capture_stream):
+                loss, info = self._forward_backward(ent["images"], ent["labels"], accumulate=False)
+                info["loss"] = loss.detach()
+        finally:
+            if self.reducer is not None:
+                self.reducer.paused = False
+        ent["graph"], ent["info"] = g, info
+        ent["ws_refs"] = list(ops._ws.values())       # scratch buffers the recorded kernels point at: must outlive the graph even if an
+                                                      # eager call with a larger shape replaces them in ops._ws later
+        ent["mask_last"], ent["backbone_last"] = self.mask_loss_fn.last, self.backbone_loss_fn.last

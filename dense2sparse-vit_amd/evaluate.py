@@ -39,10 +39,9 @@ def evaluate_performance(args, model, teacher_model, val_data_loader):
                 keep_ratio_batches.append(model.keep_ratios)
     n = max(n, 1)
     if thr and keep_ratio_batches:                                                      # :59-62
-        allr = torch.stack(keep_ratio_batches)
-        metrics["val_min_keep_ratio"] = float(allr.min())
-        metrics["val_avg_keep_ratio"] = float(allr.mean(dim=1).mean())
-        metrics["val_max_keep_ratio"] = float(allr.max())
+        from utils import keep_ratio_summary
+        (metrics["val_min_keep_ratio"], metrics["val_avg_keep_ratio"],
+         metrics["val_max_keep_ratio"]) = keep_ratio_summary(keep_ratio_batches)
     metrics["val_loss"] = running_loss / n
     metrics["val_acc"] = running_acc / n
     metrics["unpruned_acc"] = running_unpruned_acc / n

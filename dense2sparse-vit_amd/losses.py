@@ -47,7 +47,10 @@ class MaskLoss(torch.nn.Module):
             mask_loss = mask_loss + DF.RowLossFn.apply(pred_logits[i], ops.KL_PROB_TARGET, target, None, None, B)
         return mask_loss
 
-    def forward(self, pred_logits, cls_attn_weights, kept_token_idx, metrics):
+    def forward(self, pred_logits, cls_attn_weights, kept_token_idx, metrics, accumulate=True):
+        """accumulate=False: only the loss of this batch is computed (its running mean / accuracies are NOT advanced); the caller hands
+        `self.last` to accumulate() later - the split a captured (hipGraph) step needs: the kernels replay, the host-side running
+        statistics of losses.py:105-119 are advanced once per replay (d2s.engine.TrainStep)."""
         target = ops.teacher_target(cls_attn_weights.contiguous())             # losses.py:76-79
         B = target.shape[0]
         mask_loss = 0
@@ -74,13 +77,20 @@ class MaskLoss(torch.nn.Module):
                 agree = ops.mask_agreement(pm_ids, gt_ids, T)
                 mask_accs[i] = ops.sum_scalar(agree, 1.0 / float(B * T))             # :96
             mask_loss = mask_loss + DF.RowLossFn.apply(pred_logits[i], ops.KL_PROB_TARGET, target, None, None, B)   # :94-95
-        self.running_loss = self.running_loss + mask_loss.detach()
+        self.last = (mask_loss.detach(), mask_accs)
+        if accumulate:
+            self.accumulate(metrics, self.last)
+        return mask_loss
+
+    def accumulate(self, metrics, last):
+        """Advance the running mean of the loss and of the per-stage mask accuracies by one batch (losses.py:105-119)."""
+        mask_loss, mask_accs = last
+        self.running_loss = self.running_loss + mask_loss
         metrics[f"{self.phase}_mask_loss"] = self.running_loss / self.count
         for i, _ in enumerate(self.keep_ratios):
             self.runnings_accs[i] = self.runnings_accs[i] + mask_accs[i]
             metrics[f"{self.phase}_mask_acc_{i}"] = self.runnings_accs[i] / self.count
         self.count += 1
-        return mask_loss
 
 
 class BackboneLoss(torch.nn.Module):
@@ -95,7 +105,8 @@ class BackboneLoss(torch.nn.Module):
         self.running_token_dist_loss = 0
         self.runnings_acc = 0
 
-    def forward(self, logits_s, token_s, logits_t, token_t, kept_token_idx, train_labels, metrics):
+    def forward(self, logits_s, token_s, logits_t, token_t, kept_token_idx, train_labels, metrics, accumulate=True):
+        """accumulate: see MaskLoss.forward."""
         B = logits_s.shape[0]
         if self.soft_targets:      # train_labels are [B, classes] probabilities produced by the caller's mixup_fn (train.py:29-30)
             cls_loss = DF.RowLossFn.apply(logits_s, ops.SOFT_CE, train_labels.float().contiguous(), None, None, B)
@@ -112,14 +123,21 @@ class BackboneLoss(torch.nn.Module):
             # teacher tokens gathered with the LAST stage's stage-relative ids, exactly like losses.py:212
             token_kl_loss = DF.RowLossFn.apply(token_s, ops.KL_LOGIT_TARGET, token_t.detach(), kept_token_idx[-1], None, rows)   # :218-225
         backbone_loss = cls_loss + cls_kl_loss + token_kl_loss
-        self.running_loss = self.running_loss + backbone_loss.detach()
-        self.running_cls_loss = self.running_cls_loss + cls_loss.detach()
-        self.running_token_dist_loss = self.running_token_dist_loss + cls_kl_loss.detach()
-        self.running_token_kl_loss = self.running_token_kl_loss + token_kl_loss.detach()
+        self.last = (backbone_loss.detach(), cls_loss.detach(), cls_kl_loss.detach(), token_kl_loss.detach())
+        self.last_terms = self.last[1:]
+        if accumulate:
+            self.accumulate(metrics, self.last)
+        return backbone_loss
+
+    def accumulate(self, metrics, last):
+        """Advance the running means by one batch (losses.py:228-241)."""
+        backbone_loss, cls_loss, cls_kl_loss, token_kl_loss = last
+        self.running_loss = self.running_loss + backbone_loss
+        self.running_cls_loss = self.running_cls_loss + cls_loss
+        self.running_token_dist_loss = self.running_token_dist_loss + cls_kl_loss
+        self.running_token_kl_loss = self.running_token_kl_loss + token_kl_loss
         metrics["train_backbone_loss"] = self.running_loss / self.count
         metrics["train_cls_loss"] = self.running_cls_loss / self.count
         metrics["train_token_kl_loss"] = self.running_token_dist_loss / self.count      # sic: swapped in the reference
         metrics["train_cls_kl_loss"] = self.running_token_kl_loss / self.count          # (losses.py:238-239)
         self.count += 1
-        self.last_terms = (cls_loss.detach(), cls_kl_loss.detach(), token_kl_loss.detach())
-        return backbone_loss

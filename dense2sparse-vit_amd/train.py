@@ -52,10 +52,9 @@ def train_one_epoch(args, model, teacher_model, train_data_loader, optimizer, mi
         if thr and model.keep_ratios is not None:
             keep_ratio_batches.append(model.keep_ratios)
     if thr and keep_ratio_batches:                                                                   # :77-80 (the histogram plot is the caller's)
-        allr = torch.stack(keep_ratio_batches)
-        metrics["train_min_keep_ratio"] = float(allr.min())
-        metrics["train_avg_keep_ratio"] = float(allr.mean(dim=1).mean())
-        metrics["train_max_keep_ratio"] = float(allr.max())
+        from utils import keep_ratio_summary
+        (metrics["train_min_keep_ratio"], metrics["train_avg_keep_ratio"],
+         metrics["train_max_keep_ratio"]) = keep_ratio_summary(keep_ratio_batches)
     metrics["train_loss"] = float(running_loss) / max(n_steps, 1)                                    # :82
     print(f'train loss: {metrics["train_loss"]:.4f}')
     return metrics

@@ -53,17 +53,21 @@ def adjust_learning_rate(param_groups, args, step, model, warming_up_step=2, war
 class SyntheticLoader:
     """Deterministic stand-in for the ImageFolder loaders of build_data_sets.py: `steps` batches of N(0,1) images."""
 
-    def __init__(self, steps, batch, img_size=224, num_classes=1000, seed=0, device="cpu"):
+    def __init__(self, steps, batch, img_size=224, num_classes=1000, seed=0, device="cpu", last_batch=None):
+        """last_batch: size of the final batch (the reference's loaders use drop_last=False, ddp_training.py:15-20, so an epoch usually
+        ends on a shorter batch); None = as long as the others."""
         self.steps, self.batch, self.img, self.nc, self.seed, self.device = steps, batch, img_size, num_classes, seed, device
+        self.last_batch = last_batch
 
     def __len__(self):
         return self.steps
 
     def __iter__(self):
         g = torch.Generator(device=self.device).manual_seed(self.seed)
-        for _ in range(self.steps):
-            yield (torch.randn((self.batch, 3, self.img, self.img), generator=g, device=self.device),
-                   torch.randint(0, self.nc, (self.batch,), generator=g, device=self.device))
+        for i in range(self.steps):
+            b = self.last_batch if (self.last_batch and i == self.steps - 1) else self.batch
+            yield (torch.randn((b, 3, self.img, self.img), generator=g, device=self.device),
+                   torch.randint(0, self.nc, (b,), generator=g, device=self.device))
 
 
 def parse_args(argv=None):
@@ -138,3 +142,13 @@ def parse_args(argv=None):
                    help="the reference's recipe (torch.optim.AdamW over get_param_groups) instead of the fused arena step")
     p.add_argument('--gemm-mode', choices=['exact', 'split', 'bf16'], default='exact')
     return p.parse_args(argv)
+
+
+def keep_ratio_summary(keep_ratio_batches):
+    """min / avg / max of the per-image keep ratios collected over an epoch (train.py:67-70,77-80; evaluate.py:53-62).  The loaders use
+    drop_last=False (ddp_training.py:15-20), so the last batch may be shorter than the others: the batches are concatenated, never
+    stacked.  avg follows the reference: the mean of the per-batch means (sum(avg_keep_ratio) / len(loader)), min / max over all images."""
+    import torch
+    allr = torch.cat([r.reshape(-1) for r in keep_ratio_batches])
+    avg = torch.stack([r.float().mean() for r in keep_ratio_batches]).mean()
+    return float(allr.min()), float(avg), float(allr.max())

@@ -48,6 +48,13 @@ MODEL_CASES = {
                         batch=1, seed=51),
 }
 
+# Cases with no reference fixture: the reference cannot run them (its keep count is hard-coded to int(196 * ratio)), the oracle can
+# (make_cfg(init_n=...)).  BASELINE config 5 as bench.py times it by default: DeiT-Base 384x384, k = int(576 * 0.3) = 172.
+ORACLE_CASES = {
+    "base384_k30_n576": dict(cfg=O.make_cfg(img_size=384, dim=768, depth=12, heads=12, pruning_loc=(3,), token_ratio=(0.3,), init_n=576),
+                             batch=1, seed=53),
+}
+
 # Dynamic keep ratio (--patch-score-threshold): name -> dict(cfg, batch, seed, threshold).  The keep probabilities of a stage sum to 1
 # over the N tokens, so the threshold is the probability mass of the lowest-scored tokens that gets dropped.
 THRESHOLD_CASES = {

@@ -245,3 +245,16 @@ def test_bf16_data_path_host_logic():
                  a16=torch.zeros(32, 32, dtype=torch.bfloat16))
     w = torch.nn.Parameter(torch.zeros(64, 64))
     assert ops.bf16_weight(w) is None and ops.bf16_weight(w.detach()) is None and ops.bf16_weight(w, transposed=True) is None
+
+
+def test_keep_ratio_summary_handles_a_shorter_last_batch():
+    """drop_last=False loaders (ddp_training.py:15-20) end an epoch on a shorter batch: the per-image keep ratios of the batches are
+    concatenated (torch.stack would raise after the whole epoch's work); avg = mean of the per-batch means as in train.py:67-70,77-80."""
+    import torch
+    from utils import keep_ratio_summary, SyntheticLoader
+    batches = [torch.tensor([0.5, 0.7, 0.9, 0.3]), torch.tensor([0.2, 0.4, 0.6, 0.8]), torch.tensor([0.1, 1.0])]
+    mn, avg, mx = keep_ratio_summary(batches)
+    assert abs(mn - 0.1) < 1e-7 and abs(mx - 1.0) < 1e-7
+    assert abs(avg - (0.6 + 0.5 + 0.55) / 3) < 1e-6
+    sizes = [x.shape[0] for x, _ in SyntheticLoader(3, 4, img_size=8, last_batch=2)]
+    assert sizes == [4, 4, 2]

@@ -83,6 +83,30 @@ def test_mask_predictor_cli_with_dynamic_keep_ratio(capsys):
     assert "Epoch 2/2" in out and "Training complete" in out
 
 
+def test_epoch_callers_with_a_shorter_last_batch_in_threshold_mode():
+    """train_one_epoch / evaluate_performance over loaders whose last batch is shorter (drop_last=False, ddp_training.py:15-20) with
+    --patch-score-threshold set: the per-image keep ratios of all batches end up in the min / avg / max metrics."""
+    import vit_models
+    import utils
+    from d2s.engine import TrainStep
+    from train import train_one_epoch
+    from evaluate import evaluate_performance
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    kw = dict(img_size=64, embed_dim=128, depth=3, num_heads=2, num_classes=10)
+    s = vit_models.VisionTransformerDiffPruning(pruning_loc=[1], token_ratio=[0.5], distill=True, topk_selection=True,
+                                                predictor_loss_type="kl_div", patch_score_threshold=0.3, **kw).to(dev)
+    t = vit_models.VisionTransformerTeacher(**kw).to(dev)
+    args = types.SimpleNamespace(keep_ratios=[0.5], mask_loss_type="kl_div", mixup=0.0, patch_score_threshold=0.3, step=0, warmup_steps=0,
+                                 device=dev, is_sbatch=False)
+    step = TrainStep(s, t, args)
+    m = train_one_epoch(args, s, t, utils.SyntheticLoader(3, 4, 64, 10, seed=1, device=dev, last_batch=3), step, None)
+    m.update(evaluate_performance(args, s, t, utils.SyntheticLoader(3, 4, 64, 10, seed=2, device=dev, last_batch=1)))
+    for pre in ("train", "val"):
+        lo, av, hi = m[f"{pre}_min_keep_ratio"], m[f"{pre}_avg_keep_ratio"], m[f"{pre}_max_keep_ratio"]
+        assert 0.0 < lo <= av <= hi <= 1.0, (pre, lo, av, hi)
+
+
 def test_mask_loss_mse_branch_matches_reference_fixture():
     """losses.MaskLoss(mask_loss_type='mse') on the HIP path (d2s_kl_rows mode 3 + d2s_gather_renorm) against the reference's own
     output: loss, gradients of both stages' scores, and the metrics keys it writes."""

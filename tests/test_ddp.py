@@ -19,12 +19,13 @@ class _FakeArena:
         self.grads = torch.arange(n, dtype=torch.float32) * (rank + 1)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, collective="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from d2s.engine import GradReducer
     arena = _FakeArena(10000, rank)
-    red = GradReducer(arena, bucket_mb=4096 * 4 / (1 << 20))      # 4096-element buckets
+    red = GradReducer(arena, bucket_mb=4096 * 4 / (1 << 20), collective=collective)      # 4096-element buckets
+    assert red.collective == collective and red.bucket_elems == 4096
     launches = []
     orig = red._launch
     red._launch = lambda lo: (launches.append((lo, red._hi)), orig(lo))[1]
@@ -67,14 +68,24 @@ def _worker(rank, world, port, q):
     want[500:9500] = total
     ok = ok and torch.equal(arena.grads, want) and reduced[0] == (5000, 9500) and reduced[-1][0] == 500
     ok = ok and all(reduced[i][0] == reduced[i + 1][1] for i in range(len(reduced) - 1))
+    # a slice the world size does not divide (odd length): rs_ag falls back to one all_reduce for it, same sums
+    red.set_live_ranges([(0, 10000)])
+    red.live = [(3, 1000)]
+    arena.grads = torch.ones(10000) * (rank + 1)
+    red.finish()
+    want = torch.ones(10000) * (rank + 1)
+    want[3:1000] = total
+    ok = ok and torch.equal(arena.grads, want)
+    ok = ok and red._n_collectives > 0
     q.put((rank, bool(ok), spans + reduced))
     dist.destroy_process_group()
 
 
-def test_grad_reducer_gloo_world2():
+@pytest.mark.parametrize("collective,port", [("allreduce", 29517), ("rs_ag", 29519)])
+def test_grad_reducer_gloo_world2(collective, port):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, 29517, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, collective)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -83,11 +94,23 @@ def test_grad_reducer_gloo_world2():
     assert all(ok for _, ok, _ in res), res
 
 
+def test_grad_reducer_env_selects_bucket_and_collective(monkeypatch):
+    from d2s.engine import GradReducer
+    monkeypatch.setenv("D2S_DDP_BUCKET_MB", "4")
+    monkeypatch.setenv("D2S_DDP_COLLECTIVE", "rs_ag")
+    red = GradReducer(_FakeArena(64, 0))
+    assert red.bucket_elems == (4 << 20) // 4 and red.collective == "rs_ag"
+    monkeypatch.setenv("D2S_DDP_COLLECTIVE", "ring_of_fire")
+    with pytest.raises(ValueError):
+        GradReducer(_FakeArena(64, 0))
+
+
 @pytest.mark.gpu
-def test_two_ranks_match_single_process_on_concatenated_batch():
+@pytest.mark.parametrize("collective,port", [("allreduce", 29541), ("rs_ag", 29543)])
+def test_two_ranks_match_single_process_on_concatenated_batch(collective, port):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(cases.REPO, "tools", "ddp_check.py")]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+           "--master-port", str(port), os.path.join(cases.REPO, "tools", "ddp_check.py")]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", D2S_DDP_COLLECTIVE=collective)
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "[ddp_check]" in out.stdout
