@@ -74,8 +74,9 @@ def parse():
                          "per-kernel durations are meaningful - used for the rocprofv3 kernel-stats profile that has to agree with roofline.avg_launch_us")
     ap.add_argument("--batch-override", type=int, default=0,
                     help="per-GPU batch that also overrides a --config preset's batch (extra data points; config.workload names the batch that ran)")
-    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="capture the step into a hipGraph and replay it (d2s.engine.TrainStep graph mode): auto = small per-rank batches only")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="off",
+                    help="capture the step into a hipGraph and replay it (d2s.engine.TrainStep graph mode): auto = small per-rank batches only; "
+                         "off by default - measured slower than eager issue on ROCm 7.2 (profiles/r03_a_graph_vs_eager.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch-check", action="store_true",
                     help="rehearse the N-rank launch path without a GPU: the ranks rendezvous over gloo, all-reduce their rank ids and rank 0 "
@@ -438,7 +439,7 @@ def main():
     student, teacher = build(device, args.keep, arch=args.arch, locs=args.locs, keeps=args.keeps, img=args.img, init_n=args.init_n)
     targs = types.SimpleNamespace(keep_ratios=list(args.keeps), mask_loss_type="kl_div", mixup=0.0, patch_score_threshold=None, step=0)
     ts = TrainStep(student, teacher, targs, lr=5e-4, min_lr=1e-5, weight_decay=0.05, epochs=25, warmup_steps=0,
-                   distributed=distributed, graph={"auto": None, "on": True, "off": False}[args.graph])
+                   distributed=distributed, graph={"auto": "auto", "on": True, "off": False}[args.graph])
     if ts._use_graph(torch.empty((args.batch, 1), device=device)) and args.warmup < ts.GRAPH_WARM_STEPS + 1:
         args.warmup = ts.GRAPH_WARM_STEPS + 1        # the capture itself must not fall into the timed region
     if args.serial:

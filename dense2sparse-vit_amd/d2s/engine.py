@@ -206,7 +206,7 @@ class GradReducer:
     def __init__(self, arena, group=None, bucket_mb=None, collective=None):
         """bucket_mb (default: D2S_DDP_BUCKET_MB, else 16): smallest slice worth a collective of its own.
         collective (default: D2S_DDP_COLLECTIVE, else "allreduce"): "allreduce" = one all_reduce per bucket; "rs_ag" = reduce_scatter
-        into this rank's 1/world shard of the bucket (in place) followed by an all_gather of the shards - the two halves of a direct
+        into this rank's 1/world shard of the bucket followed by an all_gather of the shards - the two halves of a direct
         all-reduce over the fully connected xGMI mesh (SURVEY 8d sizes both forms); same sums, same result layout."""
         import os
         self.arena, self.group = arena, group
@@ -261,11 +261,14 @@ class GradReducer:
         n = buf.numel()
         if self.collective == "rs_ag" and self.world > 1 and n % self.world == 0:
             per = n // self.world
-            shard = buf[self.rank * per:(self.rank + 1) * per]          # in place: this rank's slot of the bucket
-            w1 = dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            shard = torch.empty(per, dtype=buf.dtype, device=buf.device)    # a buffer of its own: gloo on device tensors returns wrong sums
+            w1 = dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)   # for an aliased output
+            if async_op:
+                w1.wait()            # RCCL: a stream-level dependency, no host block; gloo's worker threads would otherwise start the
+                                     # gather before the scatter has written the shard
             w2 = dist.all_gather_into_tensor(buf, shard, group=self.group, async_op=async_op)
             self._n_collectives += 2
-            return [w1, w2] if async_op else []
+            return [w2] if async_op else []
         w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)     # also rs_ag's path for a slice the world does not divide
         self._n_collectives += 1
         return [w] if async_op else []
@@ -344,7 +347,10 @@ class TrainStep:
 
     def __init__(self, student, teacher, args, lr=5e-4, min_lr=1e-5, weight_decay=0.05, epochs=25, warmup_steps=0,
                  distributed=False, bucket_mb=None, collective=None, graph=None):
-        """graph: capture the step into a hipGraph and replay it (None: D2S_STEP_GRAPH = 0 | 1 | auto, default auto; see _use_graph)."""
+        """graph: capture the step into a hipGraph and replay it (None: D2S_STEP_GRAPH = 0 | 1 | auto, default 0; see _use_graph).
+        Off by default: on ROCm 7.2 the replay of the ~1400-node graph is SLOWER than issuing the kernels (config 3, 32 images per GPU:
+        2064 vs 2310 images/s; the replay call itself keeps the host busy for 11.4 ms against 12.5 ms of eager enqueue, and the GPU side
+        gains nothing: profiles/r03_a_graph_vs_eager.txt) - the runtime walks the graph node by node on the host."""
         from losses import MaskLoss, BackboneLoss
         self.student, self.teacher, self.args = student, teacher, args
         self.teacher.eval()
@@ -368,8 +374,8 @@ class TrainStep:
         two = os.environ.get("D2S_TEACHER_STREAM", "1") == "1" and self.arena.params.is_cuda
         self._teacher_stream = torch.cuda.Stream() if two else None
         if graph is None:
-            graph = {"0": False, "1": True}.get(os.environ.get("D2S_STEP_GRAPH", "auto"), None)
-        self.graph = graph                  # True | False | None (auto)
+            graph = {"0": False, "1": True, "auto": "auto"}[os.environ.get("D2S_STEP_GRAPH", "0")]
+        self.graph = None if graph == "auto" else bool(graph)      # True | False | None (auto: small per-rank batches only)
         self.graph_auto_max_rows = int(os.environ.get("D2S_STEP_GRAPH_AUTO_ROWS", "16384"))
         self._graphs = {}                   # key -> entry (see _graph_step)
         self._capture_stream = None
@@ -421,8 +427,29 @@ class TrainStep:
 
     def __call__(self, images, labels):
         self.arena.check_alias()
-        if self._use_graph(images):
-            return self._graph_step(images, labels)
+        if self.graph is False or not images.is_cuda:
+            return self._eager_step(images, labels)
+        # Graph-capable mode: EVERY step - the eager warm-up steps, the capture, the replays, and steps of shapes that stay eager - is
+        # issued on one side stream of this TrainStep.  Autograd pins a parameter's AccumulateGrad node to the stream of the forward that
+        # created it, and such a node outlives its step whenever anything still references that step's graph (the model's own
+        # `pred_logits` list does); a node pinned to the legacy default stream pulls that stream into a later capture, which then cannot
+        # end.  The caller's stream waits for the side stream before this returns, so the caller sees an ordinary in-order step.
+        cur = torch.cuda.current_stream()
+        if self._capture_stream is None:
+            self._capture_stream = torch.cuda.Stream()
+        side = self._capture_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            info = self._graph_step(images, labels) if self._use_graph(images) else self._eager_step(images, labels)
+        cur.wait_stream(side)
+        if not self.last_step_captured:
+            for v in info.values():            # allocated on the side stream, consumed (and freed) by the caller on its own stream
+                for t in (v if isinstance(v, (list, tuple)) else (v,)):
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(cur)
+        return info
+
+    def _eager_step(self, images, labels):
         self.last_step_captured = False
         loss, info = self._forward_backward(images, labels, accumulate=True)
         scale = self.reducer.finish() if self.reducer is not None else 1.0
@@ -477,12 +504,7 @@ class TrainStep:
             ent = self._graphs[key] = {"seen": 0, "graph": None}
         if ent["graph"] is None and ent["seen"] < self.GRAPH_WARM_STEPS:
             ent["seen"] += 1
-            self.last_step_captured = False
-            loss, info = self._forward_backward(images, labels, accumulate=True)
-            scale = self.reducer.finish() if self.reducer is not None else 1.0
-            self.opt.step(grad_scale=scale)
-            info["loss"] = loss.detach()
-            return info
+            return self._eager_step(images, labels)
         if ent["graph"] is None:
             self._capture(ent, images, labels)
         ent["images"].copy_(images, non_blocking=True)
@@ -498,9 +520,11 @@ class TrainStep:
     def _capture(self, ent, images, labels):
         if self.opt._dirty:
             self.opt._build_desc()               # host -> device copy: before the capture, not inside it
-        if self._capture_stream is None:
-            self._capture_stream = torch.cuda.Stream()
         ent["images"], ent["labels"] = images.clone(), labels.clone()
+        # references into the previous step's autograd graph that the model itself holds (they would keep its AccumulateGrad nodes alive)
+        for attr in ("pred_logits", "cls_attns", "kept_token_indices", "dropped_token_indices"):
+            if isinstance(getattr(self.student, attr, None), list):
+                setattr(self.student, attr, [])
         g = torch.cuda.CUDAGraph()
         if self.reducer is not None:
             self.reducer.paused = True

@@ -737,7 +737,7 @@ def test_bf16_gemm_mode_config5_k172_vs_oracle():
     assert max(errs) < 0.25 and np.median(errs) < 0.08
 
 
-def _full_size_properties(student, teacher, args, x, y, half, bf16=False):
+def _full_size_properties(student, teacher, args, x, y, half, bf16=False, rtol=1e-5, atol=1e-6):
     """Size-independent properties of one train step (see test_full_size_train_step_deterministic_and_batch_independent): determinism
     (bit-identical losses / ids / logits / gradients between two runs from the same state) and batch independence (the first `half`
     images alone give the same ids / logits / CLS rows as inside the full batch).  In the bf16 arithmetic mode a GEMM whose tile or
@@ -778,8 +778,8 @@ def _full_size_properties(student, teacher, args, x, y, half, bf16=False):
     else:
         for a, b in zip(part["kept"], runs[0][1]):
             np.testing.assert_array_equal(a.cpu().numpy(), b[:half].cpu().numpy())
-        np.testing.assert_allclose(part["logits_s"].cpu().numpy(), full_logits, rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(part["cls_attn"].cpu().numpy(), cls_attn[:half].cpu().numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(part["logits_s"].cpu().numpy(), full_logits, rtol=rtol, atol=atol)
+        np.testing.assert_allclose(part["cls_attn"].cpu().numpy(), cls_attn[:half].cpu().numpy(), rtol=rtol, atol=atol * 0.1)
 
 
 def test_full_size_config3_batch32_three_stages():
@@ -794,7 +794,9 @@ def test_full_size_config3_batch32_three_stages():
     args = types.SimpleNamespace(keep_ratios=[0.7, 0.5, 0.3], mask_loss_type="kl_div", mixup=0.0, patch_score_threshold=None, step=0)
     x = _t(synth.images(32, 3, 224, seed=3)).to(dev)
     y = _t(synth.labels(32, 1000, seed=3)).to(dev)
-    _full_size_properties(student, teacher, args, x, y, half=16)
+    # at 32 / 16 images the GEMM grids are small enough that the forward GEMMs split K to fill the chip (gemm_f32.hip, D2S_NT_SPLITK), and
+    # the number of K slices depends on the row count: the same products are summed in another order (measured: 2.6e-6 on O(0.5) logits)
+    _full_size_properties(student, teacher, args, x, y, half=16, rtol=1e-4, atol=1e-5)
     assert [k.shape[1] for k in student.kept_token_indices] == [137, 98, 58]
 
 
