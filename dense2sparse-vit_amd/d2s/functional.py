@@ -25,6 +25,16 @@ def _need(ctx, i):
     return ctx.needs_input_grad[i]
 
 
+def run(fn, *args):
+    """fn.apply(*args) with the grad mode decided HERE: inside Function.forward grad mode is always off and ctx.needs_input_grad only
+    reflects the inputs' requires_grad, so under torch.no_grad() a trainable model (the student in evaluate.py) would take the
+    training path - LayerNorm statistics, the GELU pre-activation copy, save_for_backward.  Detached inputs make the forward-only
+    fast paths of BlockFn / EmbedFn / PredictorFn / HeadFn the ones that run."""
+    if not torch.is_grad_enabled():
+        args = tuple(a.detach() if (torch.is_tensor(a) and a.requires_grad) else a for a in args)
+    return fn.apply(*args)
+
+
 def mode_recorded(cls):
     """Class decorator for Functions that launch GEMM / attention kernels: the forward records the arithmetic mode it ran in
     (ops.get_gemm_mode(): the process default or the caller's `with ops.gemm_mode(...)`), the backward - which autograd runs on its
@@ -146,6 +156,21 @@ class BlockFn(torch.autograd.Function):
         io = ops.bf16_io() and D % 32 == 0 and hidden % 32 == 0 and x.is_cuda
         io_attn = io and policy is None and ops._BF16_ATTENTION
         ops._SHADOW.clear()          # gradient shadows never outlive the backward pass that made them
+        ctx.composite = False
+        if policy is None and not io and ops.block_composite_ok(x, heads, hidden):
+            # fp32 data path: the whole block is ONE C-ABI call (csrc/block.hip issues the same seven launches)
+            train = any(ctx.needs_input_grad)
+            params = (n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b)
+            y, cls_row, slab = ops.block_fwd(x, params, B, n, D, heads, hidden, eps, scale, want_cls, train)
+            if train:
+                ctx.save_for_backward(x, slab, *params)
+                ctx.composite = True
+                ctx.dims = (B, n, D, heads, scale)
+                ctx.hidden = hidden
+            if cls_row is None:
+                cls_row = torch.empty((0,), device=x.device)
+            ctx.mark_non_differentiable(cls_row)
+            return y, cls_row
         if not any(ctx.needs_input_grad):
             # forward-only (the frozen teacher under no_grad, eval): no LayerNorm statistics, no GELU pre-activation copy (155 MB per
             # block at B=128), nothing saved; on the bf16 data path not even the fp32 form of the GEMM inputs
@@ -236,7 +261,25 @@ class BlockFn(torch.autograd.Function):
         return y.view(B, n, D), cls_row
 
     @staticmethod
+    def _backward_composite(ctx, gy):
+        x, slab = ctx.saved_tensors[:2]
+        params = ctx.saved_tensors[2:]
+        B, n, D, heads, scale = ctx.dims
+        wants = [_need(ctx, i) for i in range(13)]
+        dparams = [None] * 12
+        for i in range(12):
+            pair = i ^ 1 if i in (0, 1, 6, 7) else i          # a LayerNorm's weight and bias gradients are produced together
+            if wants[1 + i] or wants[1 + pair]:
+                dparams[i] = ops.grad_buffer(params[i])
+        want_dx = wants[0] or dparams[0] is not None
+        dx = ops.block_bwd(gy.contiguous(), x, slab, params, B, n, D, heads, ctx.hidden, scale, want_dx, dparams)
+        grads = [dx if wants[0] else None] + [dparams[i] if wants[1 + i] else None for i in range(12)]
+        return tuple(grads) + (None, None, None, None) + (None,) * ctx.nextra
+
+    @staticmethod
     def backward(ctx, gy, _gcls):
+        if ctx.composite:
+            return BlockFn._backward_composite(ctx, gy)
         (x, n1w, qkvw, projw, n2w, fc1w, fc2w, mean1, rstd1, ln1, qkv, ao, lse, x1, mean2, rstd2, ln2, z, h,
          n1b, qkvb, projb, n2b, fc1b, fc2b) = ctx.saved_tensors
         B, n, D, heads, scale = ctx.dims

@@ -83,6 +83,12 @@ _SIGS = {
     "d2s_perturbed_topk_workspace_bytes": (Z, [I, I, I]),
     "d2s_perturbed_topk_fwd": (I, [P, P, P, I, I, I, I, F, P, Z]),
     "d2s_perturbed_topk_bwd": (I, [P, P, P, P, I, I, I, I, F]),
+    "d2s_block_saved_floats": (L, [I, I, I, I, I, I]),
+    "d2s_block_bwd_scratch_floats": (L, [I, I, I, I, I]),
+    "d2s_block_workspace_bytes": (Z, [I, I, I, I, I]),
+    "d2s_block_wgrad_workspace_bytes": (Z, [I, I, I, I, I]),
+    "d2s_block_fwd_f32": (I, [P, P, I, I, I, I, I, F, F, P, P, P, I, I, P, Z]),
+    "d2s_block_bwd_f32": (I, [P, P, P, P, P, I, I, I, I, I, F, P, P, P, I, P, Z, P, Z, P]),
     "d2s_adamw_chunk_elems": (I, None),
     "d2s_adamw_step": (I, [P, P, P, P, P, I, F, F, F, I, F, P]),
 }

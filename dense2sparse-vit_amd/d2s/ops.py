@@ -29,6 +29,16 @@ def workspace(nbytes, device):
     return buf
 
 
+def workspace_on(stream_handle, nbytes, device):
+    """The scratch buffer of another stream than the current one (the weight-gradient stream of a composite backward call)."""
+    key = (device.type, device.index, stream_handle)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
 def _f32(t):
     assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
     return t
@@ -58,13 +68,15 @@ shadow_hits = 0                           # diagnostic: how many gradients found
 
 def shadow_put(t, t16):
     _SHADOW.clear()                       # at most one gradient is in flight between two blocks
-    _SHADOW[t.data_ptr()] = (t.numel(), t._version, t16)
+    # the entry holds the fp32 tensor itself: while it is parked here its address cannot be recycled for another tensor with the same
+    # element count and version 0 (a hook that replaces the gradient out of place would otherwise be able to alias it)
+    _SHADOW[t.data_ptr()] = (t.numel(), t._version, t16, t)
 
 
 def shadow_take(t):
     e = _SHADOW.pop(t.data_ptr(), None)
     _SHADOW.clear()
-    if e is None or e[0] != t.numel() or e[1] != t._version:
+    if e is None or e[0] != t.numel() or e[1] != t._version or e[3].untyped_storage().data_ptr() != t.untyped_storage().data_ptr():
         return None
     global shadow_hits
     shadow_hits += 1
@@ -101,6 +113,13 @@ def bf16_weight(W, transposed=False):
         _W16.clear()
     _W16[(W.data_ptr(), False)] = (weakref.ref(W), -1, W._version, shape, t16)
     return t16
+
+
+def invalidate_bf16_weights():
+    """Drop every cached bf16 form of a frozen weight.  The cache follows a weight's version counter; writes that bypass it
+    (`teacher.weight.data.copy_()`, `dist.broadcast(p.data)`, raw-pointer kernels - `.data` has a version counter of its own) must be
+    followed by this call.  vit_models' checkpoint loaders call it; arena weights are refreshed every step and need nothing."""
+    _W16.clear()
 
 
 class Bf16Weights:
@@ -600,6 +619,77 @@ def attn_bwd(qkv, out, dout, lse, B, n, H, scale, dqkv16=None, want_f32=True):
     entry = "d2s_attn_bwd_bf16" if bf16 else "d2s_attn_bwd_f32"
     lib.call(entry, lib.ptr(qkv), lib.ptr(out), lib.ptr(dout), lib.ptr(lse), lib.ptr(dqkv), lib.ptr(delta), B, n, H, float(scale))
     return dqkv
+
+
+# ---- one transformer block per C-ABI call (csrc/block.hip): the same launches as the per-op wrappers above, issued from C ----
+_BLOCK_COMPOSITE = os.environ.get("D2S_BLOCK_COMPOSITE", "1") != "0"
+_BLOCK_SIZES = {}       # (B, n, D, H, hidden, mode) -> (saved floats train, saved floats eval, bwd scratch floats, main ws bytes, wgrad ws bytes)
+c_abi_calls_saved = 0   # diagnostic: per-op calls that the composite entries replaced
+
+
+def block_composite_ok(x, heads, hidden):
+    """fp32 data path (arithmetic modes 0 / 1) on dense [B, n, H * 64] tokens; the bf16 data path keeps its per-op sequence."""
+    return _BLOCK_COMPOSITE and x.is_cuda and x.shape[2] == heads * _DH and get_gemm_mode() in (GEMM_EXACT, GEMM_SPLIT)
+
+
+_DH = 64
+
+
+def _block_sizes(B, n, D, H, hidden, mode):
+    key = (B, n, D, H, hidden, mode)
+    ent = _BLOCK_SIZES.get(key)
+    if ent is None:
+        ent = _BLOCK_SIZES[key] = (lib.query("d2s_block_saved_floats", B, n, D, H, hidden, 1), lib.query("d2s_block_saved_floats", B, n, D, H, hidden, 0),
+                                   lib.query("d2s_block_bwd_scratch_floats", B, n, D, H, hidden), lib.query("d2s_block_workspace_bytes", B, n, D, hidden, mode),
+                                   lib.query("d2s_block_wgrad_workspace_bytes", B, n, D, hidden, mode))
+    return ent
+
+
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def block_fwd(x, params, B, n, D, H, hidden, eps, scale, want_cls, train):
+    """-> (y [B,n,D], cls_row [B,H,n] or None, slab): slab holds what block_bwd needs when train, forward-only scratch otherwise."""
+    mode = get_gemm_mode()
+    sz = _block_sizes(B, n, D, H, hidden, mode)
+    slab = torch.empty((sz[0] if train else sz[1],), dtype=torch.float32, device=x.device)
+    y = torch.empty((B, n, D), dtype=torch.float32, device=x.device)
+    cls_row = torch.empty((B, H, n), dtype=torch.float32, device=x.device) if want_cls else None
+    ws = workspace(sz[3], x.device)
+    lib.call("d2s_block_fwd_f32", lib.ptr(x), _ptr_array(params), B, n, D, H, hidden, float(eps), float(scale), lib.ptr(y), lib.ptr(cls_row),
+             lib.ptr(slab), int(train), mode, lib.ptr(ws), ws.numel())
+    return y, cls_row, slab
+
+
+def block_bwd(gy, x, slab, params, B, n, D, H, hidden, scale, want_dx, dparams):
+    """dparams: 12 gradient buffers (None = not wanted; LayerNorm weight / bias come as a pair).  -> dx [B,n,D] or None"""
+    mode = get_gemm_mode()
+    sz = _block_sizes(B, n, D, H, hidden, mode)
+    dev = gy.device
+    scratch = torch.empty((sz[2],), dtype=torch.float32, device=dev)
+    dx = torch.empty((B, n, D), dtype=torch.float32, device=dev) if want_dx else None
+    ws = workspace(sz[3], dev)
+    # input gradients through the cached k-contiguous W^T copies (exact mode, arena weights, enough rows: linear_dgrad's rule)
+    wt = [None] * 4
+    if mode == GEMM_EXACT and B * n >= _DGRAD_NT_MIN_ROWS and D % 16 == 0 and hidden % 16 == 0:
+        for i, w in enumerate((params[2], params[4], params[8], params[10])):
+            if _in_weight_arena(w.data_ptr()):
+                wt[i] = transposed_weight(w)
+    side = _WGRAD["stream"] if (_WGRAD["on"] and any(dparams[i] is not None for i in (2, 3, 4, 5, 8, 9, 10, 11))) else None
+    ws_side = workspace_on(side.cuda_stream, sz[4], dev) if side is not None else None
+    lib.call("d2s_block_bwd_f32", lib.ptr(gy), lib.ptr(x), lib.ptr(slab), _ptr_array(params), _ptr_array(wt), B, n, D, H, hidden, float(scale),
+             lib.ptr(dx), _ptr_array(dparams), lib.ptr(scratch), mode, lib.ptr(ws), ws.numel(), lib.ptr(ws_side),
+             ws_side.numel() if ws_side is not None else 0, side.cuda_stream if side is not None else None)
+    if side is not None:       # autograd may free these on the main stream while the side stream still reads / writes them
+        for t in (gy, slab, scratch):
+            t.record_stream(side)
+        for t in dparams:
+            if t is not None:
+                t.record_stream(side)
+        _WGRAD["used"] = True
+    return dx
 
 
 KL_LOGIT_TARGET, KL_PROB_TARGET, CE_LABEL, MSE_TARGET, SOFT_CE = 0, 1, 2, 3, 4

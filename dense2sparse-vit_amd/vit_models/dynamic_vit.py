@@ -120,7 +120,7 @@ class Block(nn.Module):
     def forward(self, x, policy=None, return_cls_attn=False):
         a = self.attn
         extra = () if policy is None else (DF.as_policy(policy, x.shape[0], x.shape[1]),)     # :263-283 with policy -> fused policy softmax
-        y, cls_row = DF.BlockFn.apply(x, *self._params(), a.num_heads, self.norm1.eps, bool(return_cls_attn), a.scale, *extra)
+        y, cls_row = DF.run(DF.BlockFn, x, *self._params(), a.num_heads, self.norm1.eps, bool(return_cls_attn), a.scale, *extra)
         return (y, cls_row) if return_cls_attn else y
 
     def forward_ragged(self, xp, cu_seqlens, B, max_n, return_cls_attn=False):
@@ -153,7 +153,7 @@ class PatchEmbed(nn.Module):
         T = self.num_patches
         zeros_pos = torch.zeros((1, T + 1, D), dtype=torch.float32, device=x.device)
         zeros_cls = torch.zeros((1, 1, D), dtype=torch.float32, device=x.device)
-        return DF.EmbedFn.apply(x, self.proj.weight, self.proj.bias, zeros_cls, zeros_pos, self.patch_size[0])[:, 1:]
+        return DF.run(DF.EmbedFn, x, self.proj.weight, self.proj.bias, zeros_cls, zeros_pos, self.patch_size[0])[:, 1:]
 
 
 class BatchNormLayer(nn.Module):
@@ -238,15 +238,15 @@ class PredictorLG(nn.Module):
             from d2s.functional_bn import PredictorBNFn
             bns = self._bn_layers()
             running = [t for bn in bns for t in (bn.running_mean, bn.running_var)]
-            out = PredictorBNFn.apply(x_with_cls, self.training, running, *self._params())
+            out = DF.run(PredictorBNFn, x_with_cls, self.training, running, *self._params())
             if self.training:
                 for bn in bns:
                     bn.num_batches_tracked += 1
             return out
         if self.small_predictor:
             from d2s.functional_small import SmallPredictorFn
-            return SmallPredictorFn.apply(x_with_cls, *self._params())
-        return DF.PredictorFn.apply(x_with_cls, *self._params())
+            return DF.run(SmallPredictorFn, x_with_cls, *self._params())
+        return DF.run(DF.PredictorFn, x_with_cls, *self._params())
 
     def forward(self, x, policy=None, current_sigma=0.0005, cls_attn=None):
         """Reference signature: x is the CLS-free token tensor [B, N, D] (:855 passes x[:, 1:])."""
@@ -299,11 +299,11 @@ class _ViTBase(nn.Module):
 
     def _embed(self, x):
         self.patch_embed.check(x)
-        return DF.EmbedFn.apply(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.cls_token, self.pos_embed,
+        return DF.run(DF.EmbedFn, x, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.cls_token, self.pos_embed,
                                 self.patch_embed.patch_size[0])
 
     def _head(self, x):
-        return DF.HeadFn.apply(x, self.norm.weight, self.norm.bias, self.head.weight, self.head.bias, self.norm.eps)
+        return DF.run(DF.HeadFn, x, self.norm.weight, self.norm.bias, self.head.weight, self.head.bias, self.norm.eps)
 
 
 class VisionTransformerDiffPruning(_ViTBase):
@@ -560,6 +560,8 @@ def _load_local(model, checkpoint_path, strict):
         return model
     sd = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
     missing, unexpected = model.load_state_dict(checkpoint_filter_fn(sd, model), strict=strict)
+    from d2s import ops
+    ops.invalidate_bf16_weights()       # cached bf16 forms of frozen weights follow the version counter; a fresh load starts clean anyway
     print('# missing keys=', missing)
     print('# unexpected keys=', unexpected)
     return model

@@ -126,7 +126,7 @@ class T2T_ViT_Teacher(T2T_ViT):
         for blk in self.blocks:
             x, cls_row = blk(x, return_cls_attn=True)
             rows.append(cls_row.detach())
-        logits, tokens = DF.HeadFn.apply(x, self.norm.weight, self.norm.bias, self.head.weight, self.head.bias, self.norm.eps)
+        logits, tokens = DF.run(DF.HeadFn, x, self.norm.weight, self.norm.bias, self.head.weight, self.head.bias, self.norm.eps)
         return logits, tokens, torch.stack(rows, dim=1)
 
 
@@ -160,7 +160,7 @@ class T2T_ViT_DiffPruning(T2T_ViT):
                 p += 1
             x, cls_row = blk(x, return_cls_attn=True)
             self.cls_attns.append(cls_row[:, :, 1:])
-        logits, features = DF.HeadFn.apply(x, self.norm.weight, self.norm.bias, self.head.weight, self.head.bias, self.norm.eps)
+        logits, features = DF.run(DF.HeadFn, x, self.norm.weight, self.norm.bias, self.head.weight, self.head.bias, self.norm.eps)
         if self.training:
             return logits, features, self.pred_logits, self.kept_token_indices
         return logits, self.cls_attns, self.pred_logits, self.kept_token_indices

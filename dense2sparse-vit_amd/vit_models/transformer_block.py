@@ -57,7 +57,7 @@ class Block(nn.Module):
 
     def forward(self, x, return_cls_attn=False):
         a, m = self.attn, self.mlp
-        y, cls_row = DF.BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+        y, cls_row = DF.run(DF.BlockFn, x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
                                       self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
                                       a.num_heads, self.norm1.eps, bool(return_cls_attn), a.scale)
         return (y, cls_row) if return_cls_attn else y

@@ -251,6 +251,30 @@ int d2s_batchnorm_bwd(const float* x, const float* dy, const float* w, const flo
                       float* db, int relu_mask, int accumulate, int training, long R, int C, void* workspace, size_t workspace_bytes,
                       d2s_stream_t stream);
 
+/* ---- one transformer block per call (csrc/block.hip) ------------------------------------------------------------------------------
+ * Block.forward (vit_models/dynamic_vit.py:263-283: x + proj(attn(LN1 x)), then + fc2(gelu(fc1(LN2 .))), with Attention :216-236 and Mlp
+ * :169-175) and its autograd backward as ONE call each.  They issue exactly the launches of the per-op entries above (d2s_layernorm_fwd,
+ * d2s_gemm_f32, d2s_attn_fwd_f32, ... in the same order with the same arguments: bit-identical results); what they remove is the host
+ * cost of 7 + 11 separate calls per block, which bounds the step at the per-rank batches of the 8-GPU configurations (ddp_training.py:15:
+ * 256 images over 8 ranks).  fp32 data path, arithmetic modes 0 / 1.
+ * params: HOST array of 12 DEVICE pointers - norm1.weight, norm1.bias, attn.qkv.weight, attn.qkv.bias, attn.proj.weight, attn.proj.bias,
+ * norm2.weight, norm2.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias (the state-dict order of a block). */
+long d2s_block_saved_floats(int B, int n, int D, int H, int hidden, int train);   /* floats of the `saved` slab (train: what the backward needs) */
+long d2s_block_bwd_scratch_floats(int B, int n, int D, int H, int hidden);
+size_t d2s_block_workspace_bytes(int B, int n, int D, int hidden, int mode);       /* scratch of the launches on `stream` */
+size_t d2s_block_wgrad_workspace_bytes(int B, int n, int D, int hidden, int mode); /* scratch of the weight-gradient launches */
+/* x [B,n,D] -> y [B,n,D]; cls_row [B,H,n] or NULL = the CLS row of the softmax (:234); D = H * 64; train != 0 fills `saved` for the backward */
+int d2s_block_fwd_f32(const float* x, const float* const* params, int B, int n, int D, int H, int hidden, float eps, float scale, float* y,
+                      float* cls_row, float* saved, int train, int mode, void* workspace, size_t workspace_bytes, d2s_stream_t stream);
+/* gy -> dx (NULL = not wanted) and dparams (HOST array of 12 device pointers in the order of params, NULL = not wanted; a LayerNorm's
+ * weight / bias gradients come as a pair).  paramsT: NULL or HOST array {qkv.weight^T, proj.weight^T, fc1.weight^T, fc2.weight^T}
+ * (d2s_transpose_batched_f32) for NT-layout input gradients, NULL entries = NN layout.  wgrad_stream: NULL or a second stream on which the
+ * (dW, db) launches are issued after a fork from `stream` (scratch: wgrad_workspace); the caller joins the two streams before reading. */
+int d2s_block_bwd_f32(const float* gy, const float* x, const float* saved, const float* const* params, const float* const* paramsT, int B,
+                      int n, int D, int H, int hidden, float scale, float* dx, float* const* dparams, float* scratch, int mode, void* workspace,
+                      size_t workspace_bytes, void* wgrad_workspace, size_t wgrad_workspace_bytes, d2s_stream_t wgrad_stream,
+                      d2s_stream_t stream);
+
 /* ---- optimiser: torch.optim.AdamW (mask_predictor.py:229-230) over a flat arena, one launch ------------------------ */
 int d2s_adamw_chunk_elems(void);
 /* chunk_steps (n_chunks ints, device memory, zero-initialised by the caller): torch.optim.AdamW's per-parameter state['step'] - a

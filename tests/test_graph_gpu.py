@@ -150,3 +150,38 @@ def test_graph_step_full_size_config3():
     assert graph.last_step_captured, "auto mode must capture the 32-images-per-GPU step"
     big = torch.empty((128, 3, 224, 224), device=dev)
     assert not graph._use_graph(big), "auto mode leaves the 128-images-per-GPU step eager"
+
+
+@pytest.mark.parametrize("name,mode", [("micro2", 0), ("micro1", 1), ("small_3stage", 0)])
+def test_composite_block_calls_are_bit_identical_to_the_per_op_sequence(name, mode):
+    """csrc/block.hip (one C-ABI call per block forward / backward) issues the launches of the per-op path from C: same kernels, same
+    arguments, same order - so losses, ids and every gradient are bit-identical (exact and bf16x3-split arithmetic; warm-up epoch =
+    forward-only blocks, full epoch = everything; weight gradients on their own stream inside TrainStep)."""
+    from d2s import ops
+    from d2s.engine import TrainStep
+    dev = torch.device("cuda:0")
+    case = cases.MODEL_CASES[name]
+    x, y = _t(cases.make_images(case)).to(dev), _t(cases.make_labels(case)).to(dev)
+    outs = []
+    ops.set_gemm_mode(mode)
+    try:
+        for composite in (False, True):
+            ops._BLOCK_COMPOSITE = composite
+            student, teacher, _, _ = build_models(case, dev)
+            ts = TrainStep(student, teacher, make_args(case["cfg"]), warmup_steps=1, graph=False)
+            rec = []
+            for epoch in (0, 1):
+                ts.set_epoch(epoch)
+                for _ in range(2):
+                    info = ts(x, y)
+                    torch.cuda.synchronize()
+                    rec.append((info["loss"].clone(), [k.clone() for k in info["kept"]], ts.arena.grads.clone(), ts.arena.params.clone()))
+            outs.append(rec)
+    finally:
+        ops._BLOCK_COMPOSITE = True
+        ops.set_gemm_mode(ops.GEMM_EXACT)
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a[0], b[0]), (i, float(a[0]), float(b[0]))
+        assert all(torch.equal(p, q) for p, q in zip(a[1], b[1])), i
+        assert torch.equal(a[2], b[2]), f"step {i}: gradients differ"
+        assert torch.equal(a[3], b[3]), f"step {i}: parameters differ"

@@ -865,3 +865,87 @@ def test_predictor_bn_running_estimates_and_eval():
     np.testing.assert_allclose(logits.cpu().numpy(), g["eval_logits"], rtol=1e-4, atol=2e-5)
     for i, k in enumerate(kept):
         np.testing.assert_array_equal(k.cpu().numpy(), g[f"eval_kept_{i}"])
+
+
+def test_eval_under_no_grad_takes_the_forward_only_path_with_trainable_parameters():
+    """evaluate.py runs the student (parameters with requires_grad=True) under torch.no_grad(): inside Function.forward grad mode is
+    always off and needs_input_grad only mirrors requires_grad, so the decision is made before .apply() (d2s.functional.run).  Both
+    block implementations must take their forward-only branch (no statistics, no GELU pre-activation copy, nothing saved), and the
+    outputs must equal the training-path forward bit for bit."""
+    from d2s import ops
+    dev = torch.device("cuda:0")
+    case = cases.MODEL_CASES["micro2"]
+    student, _, _, _ = build_models(case, dev)
+    x = _t(cases.make_images(case)).to(dev)
+    student.eval()
+    assert all(p.requires_grad for n, p in student.named_parameters())
+    seen = []
+    orig_block, orig_ln = ops.block_fwd, ops.layernorm_fwd
+    ops.block_fwd = lambda *a: (seen.append(("block", a[-1])), orig_block(*a))[1]
+    ops.layernorm_fwd = lambda *a, **kw: (seen.append(("ln", kw.get("stats", True))), orig_ln(*a, **kw))[1]
+    try:
+        outs = {}
+        for composite in (True, False):
+            ops._BLOCK_COMPOSITE = composite
+            del seen[:]
+            with torch.no_grad():
+                outs[("nograd", composite)] = student(x)[0].clone()
+            assert seen and not any(flag for _, flag in seen), (composite, seen)          # train / stats flags all False
+            del seen[:]
+            outs[("grad", composite)] = student(x)[0].detach().clone()
+            assert any(flag for _, flag in seen), (composite, seen)                       # with grad enabled the training path runs
+    finally:
+        ops.block_fwd, ops.layernorm_fwd, ops._BLOCK_COMPOSITE = orig_block, orig_ln, True
+    ref = outs[("grad", True)]
+    for k, v in outs.items():
+        assert torch.equal(v, ref), k
+
+
+def test_perturbed_topk_default_noise_follows_torch_manual_seed():
+    """Without an explicit noise tensor / seed the noise stream is derived from torch's default generator (the reference draws from
+    it, peturbed_topk.py:29): manual_seed reproduces it, another seed changes it, successive calls differ."""
+    import vit_models
+    dev = torch.device("cuda:0")
+    x = torch.linspace(-1, 1, 2 * 48, device=dev).reshape(2, 48).contiguous()
+    def draw(seed):
+        torch.manual_seed(seed)
+        a = vit_models.PerturbedTopKFunction.apply(x, 12, 64, 0.5)
+        b = vit_models.PerturbedTopKFunction.apply(x, 12, 64, 0.5)
+        return a, b
+    a1, b1 = draw(123)
+    a2, b2 = draw(123)
+    a3, _ = draw(124)
+    assert torch.equal(a1, a2) and torch.equal(b1, b2)
+    assert not torch.equal(a1, b1) and not torch.equal(a1, a3)
+    np.testing.assert_allclose(a1.sum(dim=(1, 2)).cpu().numpy(), 12.0, rtol=1e-5)
+
+
+def test_bf16_gradient_shadow_survives_an_out_of_place_hook():
+    """bf16 data path: a block's input gradient travels to the previous block together with its bf16 copy (ops.shadow_put / shadow_take).
+    A hook that replaces the gradient out of place ((g * 2) * 0.5: the same values in a new tensor, possibly at a recycled address) must
+    make the consumer fall back to converting the fp32 gradient - never pick up a stale bf16 copy: gradients stay bit-identical."""
+    from d2s import ops
+    from d2s.engine import TrainStep
+    dev = torch.device("cuda:0")
+    case = cases.MODEL_CASES["small_k50"]
+    x, y = _t(cases.make_images(case)).to(dev), _t(cases.make_labels(case)).to(dev)
+    grads = []
+    ops.set_gemm_mode(ops.GEMM_BF16)
+    try:
+        for hook in (False, True):
+            student, teacher, _, _ = build_models(case, dev)
+            ts = TrainStep(student, teacher, make_args(case["cfg"]), warmup_steps=0, graph=False)
+            if hook:
+                student.grad_ready_hook = None
+                for blk in student.blocks[1:]:
+                    blk.register_forward_pre_hook(lambda m, inp: (inp[0].register_hook(lambda g: (g * 2.0) * 0.5), None)[1])
+            hits0 = ops.shadow_hits
+            loss, _ = ts.forward_losses(x, y)
+            ts.opt.zero_grad()
+            loss.backward()
+            torch.cuda.synchronize()
+            grads.append((ts.arena.grads.clone(), ops.shadow_hits - hits0))
+    finally:
+        ops.set_gemm_mode(ops.GEMM_EXACT)
+    assert grads[0][1] > 0, "the un-hooked run must use the shadow copies"
+    assert torch.equal(grads[0][0], grads[1][0])
