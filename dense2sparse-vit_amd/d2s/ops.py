@@ -670,7 +670,6 @@ def block_bwd(gy, x, slab, params, B, n, D, H, hidden, scale, want_dx, dparams):
     dev = gy.device
     scratch = torch.empty((sz[2],), dtype=torch.float32, device=dev)
     dx = torch.empty((B, n, D), dtype=torch.float32, device=dev) if want_dx else None
-    ws = workspace(sz[3], dev)
     # input gradients through the cached k-contiguous W^T copies (exact mode, arena weights, enough rows: linear_dgrad's rule)
     wt = [None] * 4
     if mode == GEMM_EXACT and B * n >= _DGRAD_NT_MIN_ROWS and D % 16 == 0 and hidden % 16 == 0:
@@ -679,6 +678,7 @@ def block_bwd(gy, x, slab, params, B, n, D, H, hidden, scale, want_dx, dparams):
                 wt[i] = transposed_weight(w)
     side = _WGRAD["stream"] if (_WGRAD["on"] and any(dparams[i] is not None for i in (2, 3, 4, 5, 8, 9, 10, 11))) else None
     ws_side = workspace_on(side.cuda_stream, sz[4], dev) if side is not None else None
+    ws = workspace(sz[3] if side is not None else max(sz[3], sz[4]), dev)      # in line, the weight gradients use the main scratch too
     lib.call("d2s_block_bwd_f32", lib.ptr(gy), lib.ptr(x), lib.ptr(slab), _ptr_array(params), _ptr_array(wt), B, n, D, H, hidden, float(scale),
              lib.ptr(dx), _ptr_array(dparams), lib.ptr(scratch), mode, lib.ptr(ws), ws.numel(), lib.ptr(ws_side),
              ws_side.numel() if ws_side is not None else 0, side.cuda_stream if side is not None else None)
