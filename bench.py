@@ -197,12 +197,13 @@ class KernelTimer:
         orig_call = _lib.call
 
         def counted_call(name, *a):
-            if timer.enabled:
+            if timer.counting:
                 timer.launch_calls += 1
             return orig_call(name, *a)
 
         _lib.call = counted_call
         self.launch_calls = 0
+        self.counting = False       # C-ABI calls are counted in the TIMED region (the instrumented pass issues the per-op sequence)
 
     def summary(self):
         out = {}
@@ -467,6 +468,9 @@ def main():
     # identical instrumented pass of the same K steps right after it (same process, same stream, same inputs).
     in_region = args.time_kernels_in_region and not args.no_kernel_timing
     timer.enabled = in_region
+    timer.counting = True
+    if in_region:
+        ops._BLOCK_COMPOSITE = False        # the per-kernel events sit in the per-op wrappers (see the instrumented pass below)
     if distributed:
         ts.reducer.timing = True
     host_s = 0.0
@@ -481,6 +485,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    timer.counting = False
     captured = ts.last_step_captured
     loss = float(info["loss"])
     log(f"timed region done: {args.steps} steps in {elapsed:.3f} s, loss {loss:.5f}")
@@ -492,6 +497,9 @@ def main():
         two_streams = getattr(ts, "_teacher_stream", None)
         ts._teacher_stream = None
         graph_mode, ts.graph = ts.graph, False      # per-kernel events need the kernels issued one by one
+        # ... and from the per-op wrappers the events sit in: the composite block entries (one C-ABI call per block, csrc/block.hip) issue
+        # the same launches - same kernels, arguments and order, asserted bit-identical by tests/test_graph_gpu.py - from C
+        composite, ops._BLOCK_COMPOSITE = ops._BLOCK_COMPOSITE, False
         wgrad_async, ops._WGRAD_ENABLED = ops._WGRAD_ENABLED, False      # ... and the weight gradients on the main stream
         t1 = time.perf_counter()
         for _ in range(args.steps):
@@ -504,6 +512,7 @@ def main():
         timer.enabled = False
         ts._teacher_stream = two_streams
         ts.graph = graph_mode
+        ops._BLOCK_COMPOSITE = composite
         ops._WGRAD_ENABLED = wgrad_async
         log(f"instrumented pass done: {args.steps} steps in {instr_elapsed:.3f} s")
 
@@ -540,7 +549,7 @@ def main():
         if instr_elapsed is not None:
             line["kernel_timing"] = {"method": "HIP events around every GEMM / gather / scatter / LayerNorm / AdamW launch on the launch stream, "
                                                + ("inside the timed region" if in_region else
-                                                  "in a second pass of the same K steps after the timed region (the events cost ~5 % of the step), with the teacher's forward "
+                                                  "in a second pass of the same K steps after the timed region (the events cost ~5 % of the step), issued op by op (the timed region issues a transformer block's launches through one composite C-ABI call), with the teacher's forward "
                                                   "in series with the student's and the weight-gradient GEMMs in series with the rest of backward - the timed region "
                                                   "overlaps both pairs on separate HIP streams, where per-kernel durations would read low because kernels share the GPU"),
                                      "instrumented_ms_per_step": round(1000.0 * instr_elapsed / args.steps, 3)}
