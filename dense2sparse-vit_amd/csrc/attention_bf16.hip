@@ -59,7 +59,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const QT* __restr
     const bool active = q0 < n;
     const bool want_cls = cls_row != nullptr && bx == 0 && wave == 0;
 
-    // B operand of S^T = K Q^T: this lane's query, d = 16 kk + 8 half + j, scaled, as bf16
+    // B operand of S^T = K Q^T: this lane's query, d = 16 kk + 8 half + j, scaled, as bf16 (scale = 2^-3 for 64-wide heads: the product
+    // is exact, so fp32 and bf16 qkv inputs round to the same operand).  The softmax is evaluated as 2^(s log2 e - m log2 e): one FMA and
+    // one v_exp_f32 per element - the kernel is bound by its softmax VALU work (~150 vector instructions beside 8 MFMAs per 32-key tile
+    // before round 3), not by the MFMAs
+    const float qscale = scale;
+    constexpr float L2E = 1.44269504088896340736f;
     bf16x8 qf[4];
     {
         const int qi = min(q0 + l31, n - 1);
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const QT* __restr
             f32x4 ac[2];
             load8(p + 16 * kk, ac);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { qf[kk][j] = (__bf16)(ac[0][j] * scale); qf[kk][4 + j] = (__bf16)(ac[1][j] * scale); }
+            for (int j = 0; j < 4; ++j) { qf[kk][j] = (__bf16)(ac[0][j] * qscale); qf[kk][4 + j] = (__bf16)(ac[1][j] * qscale); }
         }
     }
 
@@ -115,12 +120,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const QT* __restr
             s = mfma_bf16(kf, qf[kk], s);      // s[r] = S^T[key = row(r, half)][query = l31]
         }
         const int kv0 = t * 32;
-        float mt = -INFINITY;
+        if (kv0 + 32 > n) {          // only the last tile can hold keys past the sequence (wave-uniform)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (kv0 + mfma32_row(r, half) >= n) s[r] = -INFINITY;
-            mt = fmaxf(mt, s[r]);
+            for (int r = 0; r < 16; ++r)
+                if (kv0 + mfma32_row(r, half) >= n) s[r] = -INFINITY;
         }
+        float mt = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
         if (want_cls && l31 == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -130,19 +137,24 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const QT* __restr
         }
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = __expf(m_run - m_new);
+        const float m2 = m_new * L2E;
         float rs = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = __expf(s[r] - m_new);
+            s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], L2E, -m2));
             rs += s[r];
         }
         rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
-        // O^T columns are this lane's own query: the rescale is lane-local
+        // O^T columns are this lane's own query: the rescale is lane-local - and after the first tiles the running maximum rarely
+        // moves, so the 32 multiplies are skipped whenever no query of the wave needs them (exact: alpha == 1 for every lane then)
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * L2E);
+            l_run *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        }
+        l_run += rs;
+        m_run = m_new;
         // B operand of O^T = V^T P^T: registers r = 8 kk .. 8 kk + 7 are reduction indices 8 half .. 8 half + 7 of 16-key block kk
         bf16x8 pf[2];
 #pragma unroll
@@ -287,8 +299,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const QT* __re
     const bool active = q0 < n, qok = q0 + l31 < n;
     bf16x8 qf[4], dof[4];
     row_frags(qb, ld, q0 + l31, n, half, scale, qf);
+    constexpr float L2E = 1.44269504088896340736f;      // p = 2^(s log2 e - lse log2 e): one FMA and one v_exp_f32 per element
     row_frags(dob, ldo, q0 + l31, n, half, 1.0f, dof);
-    const float lse_i = qok ? lse[((long)b * H + h) * n + q0 + l31] : INFINITY;
+    const float lse_i = qok ? lse[((long)b * H + h) * n + q0 + l31] * 1.44269504088896340736f : INFINITY;
     const float dl_i = qok ? delta[((long)b * H + h) * n + q0 + l31] : 0.f;
     f32x16 dq[2];
 #pragma unroll
@@ -311,9 +324,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_bf16_kernel(const QT* __re
         const f32x16 dp = mma_rows(Vs, dof, l31, half);  // dP^T[key][query] = sum_d V[key][d] dO[query][d]
         const int kv0 = t * 32;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = (kv0 + mfma32_row(r, half) < n) ? __expf(s[r] - lse_i) : 0.f;
-            s[r] = p * (dp[r] - dl_i);                   // dS^T
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], L2E, -lse_i)) * (dp[r] - dl_i);      // dS^T = P^T (dP^T - delta)
+        if (kv0 + 32 > n) {          // keys past the sequence exist in the last tile only (wave-uniform)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kv0 + mfma32_row(r, half) >= n) s[r] = 0.f;
         }
         bf16x8 pf[2];
         pack2(s, pf);
@@ -347,6 +362,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const QT* __r
     const bool active = k0 < n, kok = k0 + l31 < n;
     bf16x8 kf[4], vf[4];
     row_frags(kb, ld, k0 + l31, n, half, scale, kf);     // scaled copy: only the scores use it
+    constexpr float L2E = 1.44269504088896340736f;
     row_frags(vb, ld, k0 + l31, n, half, 1.0f, vf);
     f32x16 dk[2], dv[2];
 #pragma unroll
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const QT* __r
         stage_rows(dob, ldo, row0, n, tid, dr);
         const int qi = row0 + (tid & 31), qc = min(qi, n - 1);
         const float l0 = lse_b[qc], d0 = dl_b[qc];
-        lr = qi < n ? l0 : INFINITY;                     // queries past the sequence: p = exp(s - inf) = 0
+        lr = qi < n ? l0 * L2E : INFINITY;      // queries past the sequence: p = 2^(s log2 e - inf) = 0
         dlr = qi < n ? d0 : 0.f;
     };
     fetch(0);
@@ -378,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const QT* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qi = mfma32_row(r, half);
-            const float p = __expf(s[r] - lse_s[qi]);
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], L2E, -lse_s[qi]));
             s[r] = p;
             dp[r] = p * (dp[r] - dl_s[qi]);
         }
