@@ -8,6 +8,7 @@ Reference lines (relative to /root/reference):
   GatherFn     vit_models/dynamic_vit.py:907-912
   HeadFn       vit_models/dynamic_vit.py:993-1006
 """
+import threading
 import weakref
 
 import torch
@@ -25,14 +26,28 @@ def _need(ctx, i):
     return ctx.needs_input_grad[i]
 
 
+_tls = threading.local()
+
+
 def run(fn, *args):
     """fn.apply(*args) with the grad mode decided HERE: inside Function.forward grad mode is always off and ctx.needs_input_grad only
     reflects the inputs' requires_grad, so under torch.no_grad() a trainable model (the student in evaluate.py) would take the
-    training path - LayerNorm statistics, the GELU pre-activation copy, save_for_backward.  Detached inputs make the forward-only
-    fast paths of BlockFn / EmbedFn / PredictorFn / HeadFn the ones that run."""
-    if not torch.is_grad_enabled():
-        args = tuple(a.detach() if (torch.is_tensor(a) and a.requires_grad) else a for a in args)
-    return fn.apply(*args)
+    training path - LayerNorm statistics, the GELU pre-activation copy, save_for_backward.  The flag makes the forward-only fast paths
+    of BlockFn / EmbedFn / PredictorFn / HeadFn the ones that run (the tensors themselves are passed unchanged: detached aliases would
+    defeat the identity checks of the weight caches in d2s.ops)."""
+    if torch.is_grad_enabled():
+        return fn.apply(*args)
+    prev = getattr(_tls, "no_grad", False)
+    _tls.no_grad = True
+    try:
+        return fn.apply(*args)
+    finally:
+        _tls.no_grad = prev
+
+
+def wants_grad(ctx):
+    """Does this forward have to keep anything for a backward?"""
+    return any(ctx.needs_input_grad) and not getattr(_tls, "no_grad", False)
 
 
 def mode_recorded(cls):
@@ -108,7 +123,7 @@ class EmbedFn(torch.autograd.Function):
         pos = pos_embed.reshape(T + 1, D)
         ops.gemm(ops.NT, col, Kc, w2, Kc, tokens, D, B * T, D, Kc, ops.EPI_BIAS_ROWADD, proj_b, pos[1:], D, None, T, T, 1)
         ops.fill_cls(cls_token.reshape(D), pos, tokens)
-        if any(ctx.needs_input_grad):       # forward-only callers (frozen teacher, eval) keep nothing
+        if wants_grad(ctx):       # forward-only callers (frozen teacher, eval) keep nothing
             ctx.save_for_backward(col, proj_w, proj_b, cls_token, pos_embed)
             ctx.dims = (B, T, D, Kc, tuple(proj_w.shape))
         return tokens
@@ -159,7 +174,7 @@ class BlockFn(torch.autograd.Function):
         ctx.composite = False
         if policy is None and not io and ops.block_composite_ok(x, heads, hidden):
             # fp32 data path: the whole block is ONE C-ABI call (csrc/block.hip issues the same seven launches)
-            train = any(ctx.needs_input_grad)
+            train = wants_grad(ctx)
             params = (n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b)
             y, cls_row, slab = ops.block_fwd(x, params, B, n, D, heads, hidden, eps, scale, want_cls, train)
             if train:
@@ -171,7 +186,7 @@ class BlockFn(torch.autograd.Function):
                 cls_row = torch.empty((0,), device=x.device)
             ctx.mark_non_differentiable(cls_row)
             return y, cls_row
-        if not any(ctx.needs_input_grad):
+        if not wants_grad(ctx):
             # forward-only (the frozen teacher under no_grad, eval): no LayerNorm statistics, no GELU pre-activation copy (155 MB per
             # block at B=128), nothing saved; on the bf16 data path not even the fp32 form of the GEMM inputs
             if io:
@@ -366,7 +381,7 @@ class PredictorFn(torch.autograd.Function):
         M = B * T
         x = x.contiguous()
         eps = 1e-5
-        train = any(ctx.needs_input_grad)
+        train = wants_grad(ctx)
         # bf16 arithmetic mode: as in BlockFn, each LayerNorm in front of a bf16-mode Linear also (training: only) writes the bf16 form
         # that GEMM multiplies; the weight gradients read it too.  The exact-fp32 tail keeps fp32 activations.
         io = ops.bf16_io() and x.is_cuda and D % 32 == 0
@@ -483,7 +498,7 @@ class HeadFn(torch.autograd.Function):
         B, n, D = x.shape
         M = B * n
         x = x.contiguous()
-        train = any(ctx.needs_input_grad)
+        train = wants_grad(ctx)
         xn, mean, rstd = ops.layernorm_fwd(x, ops.contiguous_map(M, D), nw, nb, M, D, eps, stats=train)
         C = hw.shape[0]
         logits = torch.empty((B, C), dtype=torch.float32, device=x.device)
