@@ -1,6 +1,7 @@
 """GPU tier: the caller-level counterparts (train.py::train_one_epoch, evaluate.py::evaluate_performance, utils.py param
 groups) run end to end on the accelerated modules, both with the fused TrainStep and with a plain torch.optim.AdamW built the
 way the reference builds it (mask_predictor.py:213-230)."""
+import os
 import types
 
 import numpy as np
@@ -180,3 +181,28 @@ def test_soft_target_cross_entropy_under_mixup():
     np.testing.assert_allclose(float(loss.detach()), float(ref.detach()), rtol=2e-5)
     np.testing.assert_allclose(ls.grad.cpu().numpy(), ls_ref.grad.numpy(), rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(tsd.grad.cpu().numpy(), ts_ref.grad.numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_bench_line_contract():
+    """`python bench.py` prints ONE JSON line with the driver's contract keys plus the `roofline` / `cpu_baseline`-style objects of this
+    scope (a short run: 2 timed steps, no CPU leg), and the per-kernel figures hang together (achieved <= peak, frac = achieved / peak, the
+    dominant kernel's launches per step is what the model issues)."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(cases.REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "host_enqueue_ms_per_step", "c_abi_calls_per_step"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "images/s" and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 128 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-3
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["achieved"] <= r["peak"] == 157.3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches_per_step"] == 159.0
+    assert d["gather"]["bound"] == "hbm" and 0 < d["gather"]["frac"] < 1 and d["c_abi_calls_per_step"] < 200
