@@ -217,7 +217,7 @@ def _in_weight_arena(ptr):
         if lo <= ptr < hi and ref() is not None:
             return True
     return False
-_DGRAD_NT_MIN_ROWS = int(os.environ.get("D2S_DGRAD_NT_MIN_ROWS", "4096"))      # below this the transpose costs more than it saves
+_DGRAD_NT_MIN_ROWS = int(os.environ.get("D2S_DGRAD_NT_MIN_ROWS", "1024"))      # arena weights get their W^T copies once per step anyway (TransposedArena); at 3168 rows the NT form is still 5-10 % faster (profiles/r03_d_config3_tile_sweep.txt)
 
 
 def bump_weights_epoch():
