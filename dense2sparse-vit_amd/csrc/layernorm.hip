@@ -287,6 +287,114 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
 }
 
+// D = 384 backward, two rows per wave (the forward's trick, ln_fwd_pair96_kernel): a row is 96 float4 = 1.5 per lane, so ln_bwd_kernel<2>
+// leaves a quarter of its load slots empty; a PAIR of rows is 192 float4 = 3 per lane and tensor, every lane busy, and the three tensors'
+// loads of a pair (x, dy, residual gradient: 9 float4 per lane) are all in flight before the first reduction.  Lane l holds vectors
+// c = l, 64 + l, 128 + l of the concatenated pair; c < 96 belongs to the first row.  Four segmented wave sums per pair (two per row, as
+// before).  A lane's accumulator slot i always covers column col[i]; every column is covered by two (lane, slot) pairs - one from each
+// row of the pair - which the block-level fold adds in a fixed order.
+__global__ __launch_bounds__(256) void ln_bwd_pair96_kernel(const float* __restrict__ x, RowMap xm, const float* __restrict__ dy,
+                                                            const float* __restrict__ w, const float* __restrict__ mean_in,
+                                                            const float* __restrict__ rstd_in, float* __restrict__ dx,
+                                                            const float* __restrict__ add_src, float* __restrict__ part, long rows,
+                                                            long rows_per_block, int relu_mask, __bf16* __restrict__ dx16) {
+    constexpr int NVEC = 96, D = 384;
+    __shared__ __attribute__((aligned(16))) float red[4][2][D];      // [wave][dw | db][column]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    int col[3];
+    bool second[3];
+    f32x4 wv[3], dw[3], db[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = lane + 64 * i;
+        second[i] = c >= NVEC;
+        col[i] = second[i] ? c - NVEC : c;
+        wv[i] = *reinterpret_cast<const f32x4*>(w + col[i] * 4);
+        dw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (long ra = r0 + 2 * wave; ra < r1; ra += 8) {
+        const bool has1 = ra + 1 < r1;
+        const long rb = has1 ? ra + 1 : ra;
+        const long oa = map_row(xm, ra), ob = map_row(xm, rb);
+        f32x4 xv[3], gv[3], av[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            xv[i] = *reinterpret_cast<const f32x4*>(x + (second[i] ? ob : oa) + col[i] * 4);
+            gv[i] = *reinterpret_cast<const f32x4*>(dy + (second[i] ? rb : ra) * D + col[i] * 4);
+            av[i] = add_src ? *reinterpret_cast<const f32x4*>(add_src + (second[i] ? ob : oa) + col[i] * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float mean_a = mean_in[ra], rstd_a = rstd_in[ra], mean_b = mean_in[rb], rstd_b = rstd_in[rb];
+        f32x4 xh[3];
+        float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float mean = second[i] ? mean_b : mean_a, rstd = second[i] ? rstd_b : rstd_a;
+            const bool live = !second[i] || has1;           // the odd last row of a block: its "second" half repeats row a and is dropped
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xh[i][j] = (xv[i][j] - mean) * rstd;
+                const float gw = gv[i][j] * wv[i][j];
+                t1 += gw;
+                t2 += gw * xh[i][j];
+                if (live) {
+                    dw[i][j] += gv[i][j] * xh[i][j];
+                    db[i][j] += gv[i][j];
+                }
+            }
+            if (second[i]) { s1b += t1; s2b += t2; } else { s1a += t1; s2a += t2; }
+        }
+        s1a = wave_sum(s1a) / (float)D;
+        s2a = wave_sum(s2a) / (float)D;
+        s1b = wave_sum(s1b) / (float)D;
+        s2b = wave_sum(s2b) / (float)D;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (second[i] && !has1) continue;
+            const float rstd = second[i] ? rstd_b : rstd_a, s1 = second[i] ? s1b : s1a, s2 = second[i] ? s2b : s2a;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = rstd * (gv[i][j] * wv[i][j] - s1 - xh[i][j] * s2);
+                if (relu_mask && !(xv[i][j] > 0.f)) o[j] = 0.f;
+                o[j] += av[i][j];
+            }
+            const long off = (second[i] ? ob : oa) + col[i] * 4;
+            *reinterpret_cast<f32x4*>(dx + off) = o;
+            if (dx16) store_bf16x4(dx16 + (second[i] ? rb : ra) * D + col[i] * 4, o);
+        }
+    }
+    if (!part) return;
+    // fold: per wave, first the (lane, slot) pairs that came from first rows, then - after a barrier - the pairs from second rows are added
+    // to the same columns; then the four waves' sums in wave order (deterministic)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (!second[i]) {
+            *reinterpret_cast<f32x4*>(&red[wave][0][col[i] * 4]) = dw[i];
+            *reinterpret_cast<f32x4*>(&red[wave][1][col[i] * 4]) = db[i];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (second[i]) {
+            f32x4 a = *reinterpret_cast<const f32x4*>(&red[wave][0][col[i] * 4]);
+            f32x4 b = *reinterpret_cast<const f32x4*>(&red[wave][1][col[i] * 4]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[j] += dw[i][j]; b[j] += db[i][j]; }
+            *reinterpret_cast<f32x4*>(&red[wave][0][col[i] * 4]) = a;
+            *reinterpret_cast<f32x4*>(&red[wave][1][col[i] * 4]) = b;
+        }
+    __syncthreads();
+    float* pw = part + (long)blockIdx.x * 2 * D;
+    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+        const int which = c >= D, cc = which ? c - D : c;
+        pw[c] = (red[0][which][cc] + red[1][which][cc]) + (red[2][which][cc] + red[3][which][cc]);
+    }
+}
+
 // fold the per-block partials: one workgroup per 64 columns of [dweight | dbias]; the 4 waves split the partial
 // index, LDS combines them in a fixed order (deterministic).
 // 1024 threads = 16 columns x 64 partial-lanes: each thread adds every 64th partial of its column (few, independent loads), LDS
@@ -468,6 +576,14 @@ static int layernorm_bwd_impl(const float* x, long rows_per_group, long group_st
         if (dx16) return D2S_ERR_ARG;      // the bf16 copy exists for the vector kernels only (D % 4 == 0)
         hipLaunchKernelGGL(ln_bwd_scalar_kernel, grid, block, (size_t)4 * 2 * D * sizeof(float), stream, x, m, dy, w, mean, rstd, dx,
                            add_src, part, rows, D, rpb, relu_mask);
+        if (dweight)
+            hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * D + FOLD_COLS - 1) / FOLD_COLS), dim3(FOLD_COLS * FOLD_LANES), 0, stream, part, nblocks, D, dweight, dbias,
+                               accumulate_wb);
+        return d2s_check_launch();
+    }
+    static const int bwd_pair_env = [] { const char* e = getenv("D2S_LN_BWD_PAIR"); return e ? atoi(e) : 1; }();
+    if (D == 384 && bwd_pair_env) {      // two rows per wave (D2S_LN_BWD_PAIR=0: the generic kernel)
+        hipLaunchKernelGGL(ln_bwd_pair96_kernel, grid, block, 0, stream, x, m, dy, w, mean, rstd, dx, add_src, part, rows, rpb, relu_mask, dx16);
         if (dweight)
             hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * D + FOLD_COLS - 1) / FOLD_COLS), dim3(FOLD_COLS * FOLD_LANES), 0, stream, part, nblocks, D, dweight, dbias,
                                accumulate_wb);
