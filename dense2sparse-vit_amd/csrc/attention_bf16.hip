@@ -10,6 +10,7 @@
 // {4-7, 12-15} (half 1) of each 16-key block.  A reduction may be walked in any order, so V^T is stored in LDS with its keys permuted
 // to that order (pos(key)) and both operands agree.
 #include "d2s_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -188,6 +189,191 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const QT* __restr
 #pragma unroll
                     for (int j = 0; j < 4; ++j) hv[j] = (__bf16)v[j];
                     *reinterpret_cast<bf16x4_t*>(out16 + po + 32 * dt + 8 * g + 4 * half) = hv;
+                }
+            }
+        if (half == 0) lse[((long)b * H + h) * n + q0 + l31] = m_run + logf(l_run);
+    }
+    if (want_cls) {
+        const float m0 = __shfl(m_run, 0, 64), il0 = __shfl(inv_l, 0, 64);
+        float* cr = cls_row + ((long)b * H + h) * n;
+        for (int j = lane; j < n; j += 64) cr[j] = expf(cls_s[j] - m0) * il0;
+    }
+}
+
+// ---- forward, 64-key tiles, V row-major with transposed reads (round 3) ---------------------------------------------------------------
+// Same orientation and outputs as attn_fwd_bf16_kernel; what changes is the tile machinery around the softmax:
+//   * 64 keys per tile: half the barriers, row maxima / sums / the rescale test once per 64 keys;
+//   * V goes to LDS row-major [key][d] with two ds_write_b128 per thread (like K) instead of 16 scalar ds_write_b16 into a transposed image;
+//     the A operand of O^T = V^T P^T (one d row, 8 consecutive keys per lane) is fetched with ds_read_b64_tr_b16, the hardware's transposing
+//     read: per 16-lane group it reads a 4-key x 16-d block and hands lane i column i.  The accumulator hands a lane the keys {0-3, 8-11}
+//     (half 0) / {4-7, 12-15} (half 1) of a 16-key block as reduction slots 0-7, i.e. exactly two 4-key blocks - no key permutation is
+//     needed any more.  Row pitch 96 bf16 (48 dwords): the 4 rows x 2 groups of a half-wave's read start on banks 0, 8, ..., 56.
+constexpr int KP2 = 72;   // K tile row pitch (bf16)
+constexpr int VP2 = 96;   // V tile row pitch (bf16): 192 B = 48 dwords (conflict-free transposed reads)
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* __restrict__ base, int off0, int off1) {      // two 4-key blocks -> 8 reduction slots
+    const bf16x4v a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4v*)(base + off0));
+    const bf16x4v b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4v*)(base + off1));
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { r[j] = a[j]; r[4 + j] = b[j]; }
+    return r;
+}
+
+template <typename QT>
+__global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel64(const QT* __restrict__ qkv, float* __restrict__ out,
+                                                                 __bf16* __restrict__ out16, float* __restrict__ lse, float* __restrict__ cls_row, int n, int H,
+                                                                 float scale) {
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * KP2];      // [key][d]
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[64 * VP2];      // [key][d]
+    extern __shared__ __attribute__((aligned(16))) float cls_s[];     // [n] raw scaled scores of query 0 (block 0 only)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    int bx, by;
+    xcd_remap_2d(bx, by);
+    const int b = by / H, h = by % H;
+    const long ld = 3L * H * DH;
+    const QT* qb = qkv + (long)b * n * ld + h * DH;
+    const QT* kb = qb + (long)H * DH;
+    const QT* vb = kb + (long)H * DH;
+    const int q0 = bx * 128 + wave * 32;
+    const bool active = q0 < n;
+    const bool want_cls = cls_row != nullptr && bx == 0 && wave == 0;
+    constexpr float L2E = 1.44269504088896340736f;
+
+    bf16x8 qf[4];
+    {
+        const int qi = min(q0 + l31, n - 1);
+        const QT* p = qb + (long)qi * ld + 8 * half;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 ac[2];
+            load8(p + 16 * kk, ac);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { qf[kk][j] = (__bf16)(ac[0][j] * scale); qf[kk][4 + j] = (__bf16)(ac[1][j] * scale); }
+        }
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // staging: thread -> (key = tid / 4 of the 64-key tile, 16 consecutive d); rows past the sequence are clamped (masked below)
+    const int skey = tid >> 2, sd16 = (tid & 3) * 16;
+    const int ntiles = (n + 63) / 64;
+    f32x4 kr[4], vr[4];
+    auto fetch = [&](int t) {
+        const long row = min(t * 64 + skey, n - 1);
+        f32x4 a[2];
+        load8(kb + row * ld + sd16, a); kr[0] = a[0]; kr[1] = a[1];
+        load8(kb + row * ld + sd16 + 8, a); kr[2] = a[0]; kr[3] = a[1];
+        load8(vb + row * ld + sd16, a); vr[0] = a[0]; vr[1] = a[1];
+        load8(vb + row * ld + sd16 + 8, a); vr[2] = a[0]; vr[3] = a[1];
+    };
+    // transposed-read addressing: lane j = 4 q + p of a 16-lane group supplies row q (a key), columns 4 p .. 4 p + 3 (d) of the block
+    const int tj = l31 & 15, tq = tj >> 2, tp = tj & 3;
+    const int v_lane = (4 * half + tq) * VP2 + 16 * (l31 >> 4) + 4 * tp;      // + 32 dt (d block) + (16 kk [+ 8]) * VP2 (key block)
+    fetch(0);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        {
+            bf16x8 h0, h1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h0[j] = (__bf16)kr[0][j]; h0[4 + j] = (__bf16)kr[1][j]; h1[j] = (__bf16)kr[2][j]; h1[4 + j] = (__bf16)kr[3][j]; }
+            *reinterpret_cast<bf16x8*>(&Ks[skey * KP2 + sd16]) = h0;
+            *reinterpret_cast<bf16x8*>(&Ks[skey * KP2 + sd16 + 8]) = h1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h0[j] = (__bf16)vr[0][j]; h0[4 + j] = (__bf16)vr[1][j]; h1[j] = (__bf16)vr[2][j]; h1[4 + j] = (__bf16)vr[3][j]; }
+            *reinterpret_cast<bf16x8*>(&Vs[skey * VP2 + sd16]) = h0;
+            *reinterpret_cast<bf16x8*>(&Vs[skey * VP2 + sd16 + 8]) = h1;
+        }
+        __syncthreads();
+        fetch(min(t + 1, ntiles - 1));
+        if (!active) continue;
+
+        f32x16 s[2];
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb2][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(32 * kb2 + l31) * KP2 + 16 * kk + 8 * half]);
+                s[kb2] = mfma_bf16(kf, qf[kk], s[kb2]);      // s[kb2][r] = S^T[key = 32 kb2 + row(r, half)][query = l31]
+            }
+        }
+        const int kv0 = t * 64;
+        if (kv0 + 64 > n) {          // only the last tile can hold keys past the sequence (wave-uniform)
+#pragma unroll
+            for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kv0 + 32 * kb2 + mfma32_row(r, half) >= n) s[kb2][r] = -INFINITY;
+        }
+        float mt = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(s[0][r], s[1][r]));
+        if (want_cls && l31 == 0) {
+#pragma unroll
+            for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + 32 * kb2 + mfma32_row(r, half);
+                    if (key < n) cls_s[key] = s[kb2][r];
+                }
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float m2 = m_new * L2E;
+        float rs = 0.f;
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[kb2][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb2][r], L2E, -m2));
+                rs += s[kb2][r];
+            }
+        rs += __shfl_xor(rs, 32, 64);
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * L2E);
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        }
+        l_run += rs;
+        m_run = m_new;
+        // B operand of O^T = V^T P^T: registers 8 q .. 8 q + 7 of s[kb2] are the reduction slots of 16-key block kk = 2 kb2 + q
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[kk >> 1][8 * (kk & 1) + j];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int base = v_lane + 32 * dt + 16 * kk * VP2;
+                const bf16x8 vf = tr_frag(Vs, base, base + 8 * VP2);
+                o[dt] = mfma_bf16(vf, pf, o[dt]);      // o[dt][r] = O^T[d = 32 dt + row(r, half)][query = l31]
+            }
+        }
+    }
+    if (!active) return;
+    const bool qok = q0 + l31 < n;
+    const float inv_l = 1.0f / l_run;
+    if (qok) {
+        const long po = ((long)b * n + q0 + l31) * H * DH + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = o[dt][4 * g + j] * inv_l;
+                if (out) *reinterpret_cast<f32x4*>(out + po + 32 * dt + 8 * g + 4 * half) = v;
+                if (out16) {
+                    bf16x4v hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hv[j] = (__bf16)v[j];
+                    *reinterpret_cast<bf16x4v*>(out16 + po + 32 * dt + 8 * g + 4 * half) = hv;
                 }
             }
         if (half == 0) lse[((long)b * H + h) * n + q0 + l31] = m_run + logf(l_run);
@@ -414,6 +600,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const QT* __r
 }  // namespace
 
 extern "C" int d2s_attn_delta(const float* out, const float* dout, float* delta, int B, int n, int H, hipStream_t stream);
+// D2S_ATTN_BF16_T64 [1]: 1 = the 64-key-tile forward with transposed V reads for long sequences (n >= 384, or where 64-key tiles pad no more
+// than 32-key tiles), 2 = always, 0 = never (the 32-key-tile kernel).  Same-call A/B: n = 577 182.4 -> 179.3 us, config 5 +0.9 %; n = 197 36.8 ->
+// 39.4 us (256 instead of 224 padded keys), hence the rule.
+static bool attn_t64(int n) {
+    static const int mode = [] { const char* e = getenv("D2S_ATTN_BF16_T64"); return e ? atoi(e) : 1; }();
+    return mode >= 2 || (mode == 1 && (n >= 384 || (n + 63) / 64 * 64 == (n + 31) / 32 * 32));
+}
 
 // Backward of the same mode (same contract as d2s_attn_bwd_f32): dqkv [B,n,3,H,64] fully written; delta_ws: [B,H,n] floats of scratch.
 template <typename QT>
@@ -434,8 +627,12 @@ int d2s_attn_fwd_bf16(const float* qkv, float* out, float* lse, float* cls_row, 
                       hipStream_t stream) {
     if (!qkv || !out || !lse || B <= 0 || n <= 0 || H <= 0 || n > 8192) return D2S_ERR_ARG;
     dim3 grid((n + 127) / 128, B * H), block(256);
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel<float>, grid, block, cls_row ? (size_t)n * sizeof(float) : 0, stream, qkv, out,
-                       static_cast<__bf16*>(nullptr), lse, cls_row, n, H, scale);
+    if (attn_t64(n))
+        hipLaunchKernelGGL(attn_fwd_bf16_kernel64<float>, grid, block, cls_row ? (size_t)n * sizeof(float) : 0, stream, qkv, out,
+                           static_cast<__bf16*>(nullptr), lse, cls_row, n, H, scale);
+    else
+        hipLaunchKernelGGL(attn_fwd_bf16_kernel<float>, grid, block, cls_row ? (size_t)n * sizeof(float) : 0, stream, qkv, out,
+                           static_cast<__bf16*>(nullptr), lse, cls_row, n, H, scale);
     return d2s_check_launch();
 }
 
@@ -447,6 +644,15 @@ int d2s_attn_fwd_bf16_bf16out(const void* qkv, int qkv_is_bf16, float* out, void
     if (!qkv || !out_bf16 || !lse || B <= 0 || n <= 0 || H <= 0 || n > 8192) return D2S_ERR_ARG;
     dim3 grid((n + 127) / 128, B * H), block(256);
     const size_t sh = cls_row ? (size_t)n * sizeof(float) : 0;
+    if (attn_t64(n)) {
+        if (qkv_is_bf16)
+            hipLaunchKernelGGL(attn_fwd_bf16_kernel64<__bf16>, grid, block, sh, stream, static_cast<const __bf16*>(qkv), out,
+                               static_cast<__bf16*>(out_bf16), lse, cls_row, n, H, scale);
+        else
+            hipLaunchKernelGGL(attn_fwd_bf16_kernel64<float>, grid, block, sh, stream, static_cast<const float*>(qkv), out,
+                               static_cast<__bf16*>(out_bf16), lse, cls_row, n, H, scale);
+        return d2s_check_launch();
+    }
     if (qkv_is_bf16)
         hipLaunchKernelGGL(attn_fwd_bf16_kernel<__bf16>, grid, block, sh, stream, static_cast<const __bf16*>(qkv), out,
                            static_cast<__bf16*>(out_bf16), lse, cls_row, n, H, scale);

@@ -1,4 +1,5 @@
 import math
+import os
 """GPU tier, per-kernel parity: every HIP entry point (called through the C ABI) against the CPU oracle / plain torch
 fp32 CPU ops on the same seeded inputs.  Integer outputs must be bit-exact; floating point within the tolerance
 written at each assert."""
@@ -701,3 +702,17 @@ def test_attention_fwd_bf16_mode(ops, B, n, H):
     np.testing.assert_allclose(cls_row.cpu().numpy().sum(-1), np.ones((B, H), np.float32), rtol=1e-4)
     err = (dqkv.cpu() - qr.grad).norm() / qr.grad.norm()
     assert float(err) < 3e-2, float(err)
+
+
+@pytest.mark.parametrize("mode", ["2", "0"])
+def test_bf16_attention_forward_both_tile_forms(mode):
+    """The bf16 attention forward exists in two tile forms - 32-key tiles with a transposed V image, and 64-key tiles with a row-major V image
+    read through ds_read_b64_tr_b16 - chosen by sequence length (D2S_ATTN_BF16_T64, read once per process).  Every bf16 attention test of
+    this file must pass with either form forced for every length."""
+    import subprocess
+    import sys
+    env = dict(os.environ, D2S_ATTN_BF16_T64=mode)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(cases.REPO, "tests", "test_kernels_gpu.py"), "-m", "gpu", "-q", "-x",
+                          "-k", "(attn or attention) and bf16 and not both_tile_forms"], env=env, capture_output=True, text=True, timeout=900, cwd=cases.REPO)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    assert " passed" in out.stdout
