@@ -29,12 +29,17 @@ def workspace(nbytes, device):
     return buf
 
 
-def workspace_on(stream_handle, nbytes, device):
-    """The scratch buffer of another stream than the current one (the weight-gradient stream of a composite backward call)."""
-    key = (device.type, device.index, stream_handle)
+def workspace_on(stream_obj, nbytes, device):
+    """The scratch buffer of another stream than the current one (the weight-gradient stream of a composite backward call) - the same
+    buffer workspace() hands out inside `with torch.cuda.stream(stream_obj)`.  A (re)allocation happens UNDER that stream: the caching
+    allocator ties a block to the stream that was current when it was allocated, and a block tied to the caller's stream would, once a
+    larger request replaces it, be handed to the caller's next tensor while launches queued on the other stream still use it (seen as a
+    wrong predictor weight gradient in the first step of one run in three, tests/test_graph_gpu.py)."""
+    key = (device.type, device.index, stream_obj.cuda_stream)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        with torch.cuda.stream(stream_obj):
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws[key] = buf
     return buf
 
@@ -677,7 +682,7 @@ def block_bwd(gy, x, slab, params, B, n, D, H, hidden, scale, want_dx, dparams):
             if _in_weight_arena(w.data_ptr()):
                 wt[i] = transposed_weight(w)
     side = _WGRAD["stream"] if (_WGRAD["on"] and any(dparams[i] is not None for i in (2, 3, 4, 5, 8, 9, 10, 11))) else None
-    ws_side = workspace_on(side.cuda_stream, sz[4], dev) if side is not None else None
+    ws_side = workspace_on(side, sz[4], dev) if side is not None else None
     ws = workspace(sz[3] if side is not None else max(sz[3], sz[4]), dev)      # in line, the weight gradients use the main scratch too
     lib.call("d2s_block_bwd_f32", lib.ptr(gy), lib.ptr(x), lib.ptr(slab), _ptr_array(params), _ptr_array(wt), B, n, D, H, hidden, float(scale),
              lib.ptr(dx), _ptr_array(dparams), lib.ptr(scratch), mode, lib.ptr(ws), ws.numel(), lib.ptr(ws_side),

@@ -39,7 +39,12 @@ def _same_step(eager, graph, x, y, tag):
     for a, b in zip(ie["kept"], ig["kept"]):
         assert torch.equal(a, b), tag
     assert torch.equal(ie["logits_s"].detach(), ig["logits_s"].detach()), tag
-    assert torch.equal(eager.arena.grads, graph.arena.grads), f"{tag}: gradients differ"
+    if not torch.equal(eager.arena.grads, graph.arena.grads):
+        d = (eager.arena.grads - graph.arena.grads).abs()
+        bad = torch.nonzero(d > 0).flatten()
+        names = sorted({eager.arena.names[max(i for i, o in enumerate(eager.arena.offsets) if o <= int(j))] for j in bad[:: max(1, bad.numel() // 64)]})
+        raise AssertionError(f"{tag}: gradients differ in {bad.numel()} elements, max abs {float(d.max()):.3e} (max |g| {float(eager.arena.grads.abs().max()):.3e}); "
+                             f"first offset {int(bad[0])}; tensors: {names[:12]}")
     assert torch.equal(eager.arena.params, graph.arena.params), f"{tag}: parameters differ after the update"
     assert torch.equal(eager.opt.exp_avg_sq, graph.opt.exp_avg_sq), tag
 
