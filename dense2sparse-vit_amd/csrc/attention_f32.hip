@@ -19,6 +19,15 @@
 
 namespace {
 
+#ifdef D2S_ATTN_STAMPS   // diagnostic build only (tools/attn_stamps.py): per-workgroup phase stamps in shader cycles + 100 MHz wall ticks
+__device__ unsigned long long g_attn_stamps[16 * 8192];
+#define ASTAMP(i) if (threadIdx.x == 0) { const int L_ = blockIdx.y * gridDim.x + blockIdx.x; if (L_ < 8192) g_attn_stamps[16 * L_ + (i)] = __builtin_amdgcn_s_memtime(); }
+#define ASTAMPR(i) if (threadIdx.x == 0) { const int L_ = blockIdx.y * gridDim.x + blockIdx.x; if (L_ < 8192) g_attn_stamps[16 * L_ + (i)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define ASTAMP(i)
+#define ASTAMPR(i)
+#endif
+
 constexpr int DH = 64;
 constexpr int PITCH = 68;  // floats; 16-B aligned rows, conflict-free ds_read_b128 for 16 distinct rows
 
@@ -126,6 +135,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float cls_s[];  // [n] raw scaled scores of query 0 (block 0 only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int H = a.H;
+    ASTAMP(0); ASTAMPR(8);
     int bx, by;
     xcd_remap_2d(bx, by);      // all blocks of one head on one XCD (shared K / V / Q / dO panels stay in its L2)
     const int b = by / H, h = by % H;
@@ -169,6 +179,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdArgs a) {
             vacc += vr[1];
         }
         __syncthreads();
+        if (t == 0) { ASTAMP(1); }
+        if (t == 1) { ASTAMP(2); }
+        if (t == 2) { ASTAMP(3); }
         if (t + 1 < ntiles) {
             tile_load(kb, ld, (t + 1) * 32, n, tid, kr);
             tile_load(vb, ld, (t + 1) * 32, n, tid, vr);
@@ -217,6 +230,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdArgs a) {
         }
         mma_lds_reg_t(s, Vs, l31, half, o, min(4, (n - kv0 + 7) >> 3));
     }
+    ASTAMP(4);
     const float c = POLICY ? a.eps / (float)n : 0.f;
     if (POLICY) {   // fold the 16 per-thread partial column sums of every column quad (threads with equal tid & 15) -> vsum_s[64]
         *reinterpret_cast<f32x4*>(&vred[(tid >> 4) * 64 + (tid & 15) * 4]) = vacc;
@@ -262,6 +276,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdArgs a) {
             cr[j] = e * il0;
         }
     }
+    ASTAMP(5); ASTAMPR(9);
 }
 
 // delta[b,h,i] = sum_d dout[b,i,h,d] * out[b,i,h,d]
@@ -456,6 +471,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
 }
 
 }  // namespace
+
+#ifdef D2S_ATTN_STAMPS
+extern "C" int d2s_debug_read_attn_stamps(unsigned long long* host_out, int n_wg) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), (size_t)n_wg * 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" {
 
