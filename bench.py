@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="off",
                     help="capture the step into a hipGraph and replay it (d2s.engine.TrainStep graph mode): auto = small per-rank batches only; "
                          "off by default - measured slower than eager issue on ROCm 7.2 (profiles/r03_a_graph_vs_eager.txt)")
+    ap.add_argument("--lookahead", choices=["on", "off"], default="off",
+                    help="hand TrainStep the NEXT batch as well (here: the same synthetic batch), so that the frozen teacher's forward for step "
+                         "t+1 is issued during step t and shares the GPU with its backward; one teacher forward per step either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch-check", action="store_true",
                     help="rehearse the N-rank launch path without a GPU: the ranks rendezvous over gloo, all-reduce their rank ids and rank 0 "
@@ -454,9 +457,10 @@ def main():
     images = torch.randn((args.batch, 3, args.img, args.img), device=device, generator=g)
     labels = torch.randint(0, 1000, (args.batch,), device=device, generator=g)
 
+    nxt = images if args.lookahead == "on" else None
     log(f"models built on {device}; {args.warmup} warm-up steps")
     for i in range(args.warmup):
-        ts(images, labels)
+        ts(images, labels, nxt)
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
     torch.cuda.synchronize()
@@ -477,7 +481,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         h0 = time.perf_counter()
-        info = ts(images, labels)
+        info = ts(images, labels, nxt)
         host_s += time.perf_counter() - h0       # time the host spends issuing one step (no synchronisation inside)
     torch.cuda.synchronize()
     if distributed:

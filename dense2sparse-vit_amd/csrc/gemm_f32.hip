@@ -1086,11 +1086,14 @@ int d2s_linear_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, f
 }
 // The same in mode 2 with the layer input given in bf16 only (x_bf16 [tokens][n_in], row stride ldx elements): what the bf16 data path
 // saved for the backward instead of the fp32 activation.  dy is fp32 (its exact column sums are the bias gradient) or, when the kernel that
-// produced it wrote bf16 only, dy_bf16 [tokens][n_out] (dy may be NULL; the bias gradient is then the sum of the bf16 values).
+// produced it wrote bf16 only, dy_bf16 [tokens][n_out] (dy may be NULL; the bias gradient is then the sum of the bf16 values).  BOTH may be
+// given (dy_bf16 = dy rounded to bf16, e.g. by the LayerNorm backward that produced dy): the matrix kernel then reads the two bf16 operands
+// token-major as they lie - no transposing pass - and the bias gradient is still the exact column sum of dy; results are bit-identical
+// to the dy-only call.
 int d2s_linear_wgrad_f32_bf16x(const float* dy, const void* dy_bf16, long lddy, const void* x_bf16, long ldx, float* dW, long lddw, float* db,
                                int tokens, int n_out, int n_in, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!x_bf16 || (!dy && !dy_bf16)) return D2S_ERR_ARG;
-    return gemm_impl(2, dy_bf16 ? nullptr : dy, lddy, nullptr, ldx, dW, lddw, n_out, n_in, tokens, EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0,
+    return gemm_impl(2, dy, lddy, nullptr, ldx, dW, lddw, n_out, n_in, tokens, EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0,
                      accumulate, workspace, workspace_bytes, stream, db, 2, x_bf16, nullptr, dy_bf16);
 }
 

@@ -411,8 +411,18 @@ __device__ __forceinline__ void wait_vm_then_barrier() {      // counted wait fo
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");      // "memory": fragment reads stay behind it
 }
 
-template <int WGN, int BK, int NS>
+// TOK (weight gradients on the bf16 data path, both operands at hand in bf16): the operands are read where they lie, TOKEN-major -
+// q.Ap = dy [K tokens][M] (row stride p.lda), q.Bp = x [K tokens][N] (p.ldb) - and no transposing pass runs first.  A slab is 64 tokens
+// x 256 features per operand, kept as two [64 tokens][128 features] images of 256-byte rows with the chunk swizzle of the CDNA guide's
+// dual-use image (chunk ^ ((row & 3) << 2 | (row >> 2) & 3), applied to the DMA's source address), and the MFMA fragments - 8 tokens of
+// one feature per lane - come out of ds_read_b64_tr_b16 (two 4-token blocks each): 12 transposing reads per 8 MFMAs instead of 6
+// ds_read_b128, nothing else in the loop changes.  WGN = 4, BK = 64 only; K % 64 == 0, M % 8 == N % 8 == 0.
+__device__ __forceinline__ int tok_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+typedef __bf16 bf16x4t __attribute__((ext_vector_type(4)));
+
+template <int WGN, int BK, int NS, bool TOK = false>
 __global__ __launch_bounds__(WGN * 128, 2) void gemm_bf16_dma_kernel(GemmArgs p, PieceArgs q) {
+    static_assert(!TOK || (WGN == 4 && BK == 64), "token-major form: 256x256 tiles, 64-token slabs");
     constexpr int BM = 256, BN = 64 * WGN, NW = 2 * WGN, RB = BK * 2, KS = BK / 16;
     constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, STAGE = A_BYTES + B_BYTES;
     constexpr int NA = A_BYTES / 1024 / NW, NB = B_BYTES / 1024 / NW;      // 1 KB wave-instructions per wave per slab
@@ -445,13 +455,23 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm_bf16_dma_kernel(GemmArgs p,
     unsigned offa[NA], offb[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int o = (wave * NA + i) * 1024 + lane * 16, row = o / RB, ch = (o % RB) / 16;
-        offa[i] = (unsigned)(min(row0 + row, p.M - 1)) * (unsigned)(q.Kp * 2) + (unsigned)((ch ^ dma_swz<BK>(row)) * 16);
+        if constexpr (TOK) {      // 1 KB piece g = 4 token rows of feature half g >> 4; a lane brings logical chunk (lane & 15) ^ swz(row)
+            const int g = wave * NA + i, row = 4 * (g & 15) + (lane >> 4), ch = (lane & 15) ^ tok_swz(row);
+            offa[i] = (unsigned)row * (unsigned)(p.lda * 2) + (unsigned)(min(row0 + 128 * (g >> 4) + 8 * ch, p.M - 8) * 2);
+        } else {
+            const int o = (wave * NA + i) * 1024 + lane * 16, row = o / RB, ch = (o % RB) / 16;
+            offa[i] = (unsigned)(min(row0 + row, p.M - 1)) * (unsigned)(q.Kp * 2) + (unsigned)((ch ^ dma_swz<BK>(row)) * 16);
+        }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int o = (wave * NB + i) * 1024 + lane * 16, row = o / RB, ch = (o % RB) / 16;
-        offb[i] = (unsigned)(min(col0 + row, p.N - 1)) * (unsigned)(q.Kp * 2) + (unsigned)((ch ^ dma_swz<BK>(row)) * 16);
+        if constexpr (TOK) {
+            const int g = wave * NB + i, row = 4 * (g & 15) + (lane >> 4), ch = (lane & 15) ^ tok_swz(row);
+            offb[i] = (unsigned)row * (unsigned)(p.ldb * 2) + (unsigned)(min(col0 + 128 * (g >> 4) + 8 * ch, p.N - 8) * 2);
+        } else {
+            const int o = (wave * NB + i) * 1024 + lane * 16, row = o / RB, ch = (o % RB) / 16;
+            offb[i] = (unsigned)(min(col0 + row, p.N - 1)) * (unsigned)(q.Kp * 2) + (unsigned)((ch ^ dma_swz<BK>(row)) * 16);
+        }
     }
     const unsigned char* Ag = reinterpret_cast<const unsigned char*>(q.Ap);
     const unsigned char* Bg = reinterpret_cast<const unsigned char*>(q.Bp);
@@ -459,13 +479,15 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm_bf16_dma_kernel(GemmArgs p,
     auto issue = [&](int kt, int buf) {
         unsigned char* st = smem_raw + buf * STAGE;
         const unsigned kb = (unsigned)(kbeg * 2) + (unsigned)kt * RB;
+        const unsigned ka = TOK ? (unsigned)(kbeg + kt * BK) * (unsigned)(p.lda * 2) : kb;      // token-major: the slab is BK token ROWS
+        const unsigned kbb = TOK ? (unsigned)(kbeg + kt * BK) * (unsigned)(p.ldb * 2) : kb;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ag + offa[i] + kb),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ag + offa[i] + ka),
                                              (__attribute__((address_space(3))) void*)(st + (wave * NA + i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bg + offb[i] + kb),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bg + offb[i] + kbb),
                                              (__attribute__((address_space(3))) void*)(st + A_BYTES + (wave * NB + i) * 1024), 16, 0, 0);
     };
 
@@ -484,11 +506,47 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm_bf16_dma_kernel(GemmArgs p,
 #pragma unroll
     for (int t = 0; t < 2; ++t) { const int row = wn * 64 + t * 32 + l31; rb[t] = A_BYTES + row * RB; sb[t] = dma_swz<BK>(row); }
 
+    // token-major form: byte offset of this lane's address for the transposing read of (32-feature tile t, 4-token block blk) at K step 0;
+    // a K step is 16 token rows = 4096 bytes further on (the swizzle does not depend on it).  Lane 4q + p of a 16-lane group addresses
+    // token row q of the block, features 4p .. 4p + 3 of the group's 16.
+    int ta[4][2], tb[2][2];
+    if constexpr (TOK) {
+        const int g2 = l31 >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int row = 8 * half + 4 * blk + tq, f = tok_swz(row);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                ta[t][blk] = wm * 16384 + 256 * row + 16 * ((4 * t + 2 * g2 + (tp >> 1)) ^ f) + 8 * (tp & 1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                tb[t][blk] = A_BYTES + (wn >> 1) * 16384 + 256 * row + 16 * ((8 * (wn & 1) + 4 * t + 2 * g2 + (tp >> 1)) ^ f) + 8 * (tp & 1);
+        }
+    }
+    auto trf = [&](const unsigned char* st, int off) {
+        const bf16x4t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4t*)(st + off));
+        return lo;
+    };
     auto rd = [&](const unsigned char* st, int ks, bf16x8 (&a)[4], bf16x8 (&b)[2]) {
+        if constexpr (TOK) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bf16x4t lo = trf(st, tb[t][0] + ks * 4096), hi = trf(st, tb[t][1] + ks * 4096);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { b[t][j] = lo[j]; b[t][4 + j] = hi[j]; }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x4t lo = trf(st, ta[t][0] + ks * 4096), hi = trf(st, ta[t][1] + ks * 4096);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { a[t][j] = lo[j]; a[t][4 + j] = hi[j]; }
+            }
+        } else {
 #pragma unroll
         for (int t = 0; t < 2; ++t) b[t] = *reinterpret_cast<const bf16x8*>(st + rb[t] + (((2 * ks + half) ^ sb[t]) << 4));
 #pragma unroll
         for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const bf16x8*>(st + ra[t] + (((2 * ks + half) ^ sa[t]) << 4));
+        }
     };
     auto mm_head = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[2]) { acc[0][0] = mfma_bf16(a[0], b[0], acc[0][0]); };
     auto mm_tail = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[2]) {
@@ -556,7 +614,7 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm_bf16_dma_kernel(GemmArgs p,
     }
 }
 
-template <int WGN, int BK, int NS>
+template <int WGN, int BK, int NS, bool TOK = false>
 inline void launch_dma(const GemmArgs& pv, const PieceArgs& q, hipStream_t stream) {
     constexpr int BN = 64 * WGN;
     constexpr size_t lds = (size_t)NS * (256 + BN) * BK * 2;
@@ -564,14 +622,14 @@ inline void launch_dma(const GemmArgs& pv, const PieceArgs& q, hipStream_t strea
     static_assert(lds <= 160 * 1024, "LDS per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WGN, BK, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WGN, BK, NS, TOK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int tiles = ((pv.M + 255) / 256) * ((pv.N + BN - 1) / BN) * ((q.Kp + pv.k_per_slice - 1) / pv.k_per_slice);
     static const int persist_env = [] { const char* e = getenv("D2S_DMA_PERSISTENT"); return e ? atoi(e) : 1; }();
     const int resident = gemm_cus() * (WGN == 4 ? 1 : 2);      // one 256x256 or two 256x128 workgroups per CU
     const int grid = (persist_env && tiles > resident) ? resident : tiles;
-    hipLaunchKernelGGL((gemm_bf16_dma_kernel<WGN, BK, NS>), dim3(grid), dim3(WGN * 128), lds, stream, pv, q);
+    hipLaunchKernelGGL((gemm_bf16_dma_kernel<WGN, BK, NS, TOK>), dim3(grid), dim3(WGN * 128), lds, stream, pv, q);
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -697,6 +755,42 @@ int split_tn_dma_slices(int M, int N, int K) {
     return slices < 1 ? 1 : slices;
 }
 
+// Per-64-token partial column sums of a token-major bf16 matrix, [K / 64][R] floats, summed in the order split_cols_kernel uses (four runs
+// of 16 tokens, then (0 + 1) + (2 + 3)): the bias gradient's partials when no transposing pass reads dy (token-major weight gradient).
+template <typename ST>
+__global__ __launch_bounds__(256) void colsum_tok_kernel(const ST* __restrict__ src, long ld, int R, float* __restrict__ colsum_part) {
+    // block = 64 tokens x 256 columns; thread (q, c4): 16 tokens of 4 columns, 16 independent 16- / 8-byte loads (R % 4 == 0, ld % 4 == 0)
+    __shared__ f32x4 part[4][64];
+    const int q = threadIdx.x >> 6, c4 = threadIdx.x & 63, c = blockIdx.x * 256 + 4 * c4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (c < R) {
+        const ST* p = src + ((long)blockIdx.y * 64 + q * 16) * ld + c;
+        f32x4 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if constexpr (sizeof(ST) == 4) {
+                v[k] = *reinterpret_cast<const f32x4*>(p + (long)k * ld);
+            } else {
+                const bf16x4t h = *reinterpret_cast<const bf16x4t*>(p + (long)k * ld);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[k][j] = (float)h[j];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += v[k][j];
+    }
+    part[q][c4] = s;
+    __syncthreads();
+    if (q == 0 && c < R) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (part[0][c4][j] + part[1][c4][j]) + (part[2][c4][j] + part[3][c4][j]);
+        *reinterpret_cast<f32x4*>(colsum_part + (long)blockIdx.y * R + c) = o;
+    }
+}
+
 // colsum_part (optional, [split_tn_colsum_partials(K)][M] floats): per-64-token partial column sums of A (= dy), produced by the split
 // pass that reads dy anyway; the caller folds them in order into the bias gradient.
 int split_tn_colsum_partials(int K) { return tn_kp(K) / 64; }
@@ -707,8 +801,25 @@ int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_
     __bf16* Ap = static_cast<__bf16*>(pieces_ws);
     __bf16* Bp = reinterpret_cast<__bf16*>(static_cast<unsigned char*>(pieces_ws) + align256((size_t)split * p.M * Kp * sizeof(__bf16)));
     dim3 block(256);
-    if (p.b16)      // bf16 data path: dy handed over in bf16 (the gradient a GEMM epilogue / attention backward wrote in that form only); its
-                    // column sums - the bias gradient - are then sums of the bf16 values, as under torch.autocast
+    // Both operands at hand in bf16 (the bf16 data path's fc1 / qkv, and proj / fc2 where the caller kept the bf16 forms): the matrix kernel
+    // reads them token-major as they lie (gemm_bf16_dma_kernel<.., TOK>) - no transposing pass, no piece matrices.  D2S_TN_TOKEN_MAJOR=0: A/B.
+    static const int tok_env = [] { const char* e = getenv("D2S_TN_TOKEN_MAJOR"); return e ? atoi(e) : 1; }();
+    if (tok_env && p.b16 && p.a16 && p.K % 64 == 0 && p.M % 8 == 0 && p.N % 8 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 &&
+        (reinterpret_cast<uintptr_t>(p.b16) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.a16) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && split_tn_use_dma(p.M, p.N, p.K) &&
+        epilogue_vec_ok(p) && p.slab_stride % 4 == 0 && p.k_per_slice % 64 == 0 && (long)p.K * p.lda * 2 < (1L << 32) && (long)p.K * p.ldb * 2 < (1L << 32)) {
+        if (colsum_part && p.A)       // the fp32 gradient exists too: the bias gradient stays its exact column sum
+            hipLaunchKernelGGL(colsum_tok_kernel<float>, dim3((p.M + 255) / 256, p.K / 64), block, 0, stream, p.A, p.lda, p.M, colsum_part);
+        else if (colsum_part)
+            hipLaunchKernelGGL(colsum_tok_kernel<__bf16>, dim3((p.M + 255) / 256, p.K / 64), block, 0, stream, static_cast<const __bf16*>(p.b16), p.lda, p.M, colsum_part);
+        GemmArgs pt = p;
+        pt.vec_epilogue = 1;
+        pt.a16 = nullptr; pt.c16 = nullptr; pt.b16 = nullptr;
+        PieceArgs qt{static_cast<const __bf16*>(p.b16), static_cast<const __bf16*>(p.a16), p.K};
+        launch_dma<4, 64, 2, true>(pt, qt, stream);
+        return d2s_check_launch();
+    }
+    if (p.b16 && !p.A)   // bf16 data path: dy handed over in bf16 ONLY (the gradient a GEMM epilogue / attention backward wrote in that form); its
+                         // column sums - the bias gradient - are then sums of the bf16 values, as under torch.autocast
         hipLaunchKernelGGL((split_cols_kernel<1, __bf16>), dim3((p.M + 63) / 64, (Kp + 63) / 64), block, 0, stream, static_cast<const __bf16*>(p.b16), p.lda, Ap,
                            p.M, p.K, Kp, (int)((p.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.b16) & 7) == 0)), colsum_part);
     else

@@ -379,6 +379,7 @@ class TrainStep:
         self.graph_auto_max_rows = int(os.environ.get("D2S_STEP_GRAPH_AUTO_ROWS", "16384"))
         self._graphs = {}                   # key -> entry (see _graph_step)
         self._capture_stream = None
+        self._ahead = None                  # teacher outputs of the next batch, issued one step early (_teacher_ahead)
         self.last_step_captured = False     # diagnostic: did the last call replay a graph
         self.set_epoch(0)
 
@@ -395,24 +396,51 @@ class TrainStep:
                 if p.requires_grad and g is not None and g != "early_exit")
         return out
 
-    def forward_losses(self, images, labels, accumulate=True):
+    @staticmethod
+    def _batch_key(images):
+        return (images.data_ptr(), images._version, tuple(images.shape))
+
+    def _teacher_ahead(self, images, ready):
+        """Issue the frozen teacher's forward for the NEXT batch on the teacher stream now (it depends on nothing this step computes),
+        so that it shares the GPU with this step's backward instead of with the next step's student forward.  `ready`: event on the
+        caller's stream after which `images` is valid."""
+        side = self._teacher_stream
+        side.wait_event(ready)
+        with torch.cuda.stream(side), torch.no_grad():
+            out = self.teacher(images)
+            done = side.record_event()
+        images.record_stream(side)
+        self._ahead = dict(key=self._batch_key(images), images=images, out=out, done=done)
+
+    def forward_losses(self, images, labels, accumulate=True, next_images=None):
+        ahead, self._ahead = self._ahead, None
+        if ahead is not None and (self._teacher_stream is None or ahead["key"] != self._batch_key(images)):
+            ahead = None                                # a different batch arrived than the one announced: its teacher pass is dropped
         if self._teacher_stream is not None:
             # The frozen teacher's forward and the student's forward are independent until the losses: the teacher runs on a second
             # HIP stream so that its kernels fill the CUs the student's kernels leave idle in their ramp-up / last residency round
             # (and vice versa).  Scratch buffers are per stream (ops.workspace), so the two forwards never share one.
             from .functional import shared_patch_columns, prime_patch_columns
             side, main = self._teacher_stream, torch.cuda.current_stream()
-            with shared_patch_columns():
-                pe = getattr(self.student, "patch_embed", None)
-                if pe is not None and images.is_contiguous() and hasattr(pe, "patch_size") and getattr(self.teacher, "patch_embed", None) is not None:
-                    prime_patch_columns(images, pe.patch_size[0])       # one im2col for both, built before the fork
-                side.wait_stream(main)
-                with torch.cuda.stream(side), torch.no_grad():
-                    logits_t, token_t, cls_attn = self.teacher(images)
+            ready = main.record_event() if next_images is not None else None
+            if ahead is not None:                       # issued during the previous step (_teacher_ahead)
+                logits_t, token_t, cls_attn = ahead["out"]
                 logits_s, token_s, pred_logits, kept = self.student(images)
-                main.wait_stream(side)
+                main.wait_event(ahead["done"])
+            else:
+                with shared_patch_columns():
+                    pe = getattr(self.student, "patch_embed", None)
+                    if pe is not None and images.is_contiguous() and hasattr(pe, "patch_size") and getattr(self.teacher, "patch_embed", None) is not None:
+                        prime_patch_columns(images, pe.patch_size[0])       # one im2col for both, built before the fork
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side), torch.no_grad():
+                        logits_t, token_t, cls_attn = self.teacher(images)
+                    logits_s, token_s, pred_logits, kept = self.student(images)
+                    main.wait_stream(side)
             for t in (logits_t, token_t, cls_attn):      # produced on the side stream, consumed (and later freed) on the main one
                 t.record_stream(main)
+            if next_images is not None:
+                self._teacher_ahead(next_images, ready)
         else:
             from .functional import shared_patch_columns
             with shared_patch_columns():       # teacher and student embed the same images: one im2col pass for both
@@ -425,10 +453,13 @@ class TrainStep:
         return loss, dict(mask_loss=mask_loss, backbone_loss=backbone_loss, kept=kept, logits_s=logits_s, token_s=token_s,
                           pred_logits=pred_logits, logits_t=logits_t, token_t=token_t, cls_attn=cls_attn)
 
-    def __call__(self, images, labels):
+    def __call__(self, images, labels, next_images=None):
+        """next_images: the batch of the FOLLOWING call, if the caller already has it (a prefetching loader does).  The frozen teacher's
+        forward for it is then issued during this step (see _teacher_ahead) - every step still runs exactly one teacher forward, the
+        results are bit-identical, and a following call with any other batch simply recomputes.  Eager steps only."""
         self.arena.check_alias()
         if self.graph is False or not images.is_cuda:
-            return self._eager_step(images, labels)
+            return self._eager_step(images, labels, next_images)
         # Graph-capable mode: EVERY step - the eager warm-up steps, the capture, the replays, and steps of shapes that stay eager - is
         # issued on one side stream of this TrainStep.  Autograd pins a parameter's AccumulateGrad node to the stream of the forward that
         # created it, and such a node outlives its step whenever anything still references that step's graph (the model's own
@@ -449,18 +480,18 @@ class TrainStep:
                         t.record_stream(cur)
         return info
 
-    def _eager_step(self, images, labels):
+    def _eager_step(self, images, labels, next_images=None):
         self.last_step_captured = False
-        loss, info = self._forward_backward(images, labels, accumulate=True)
+        loss, info = self._forward_backward(images, labels, accumulate=True, next_images=next_images)
         scale = self.reducer.finish() if self.reducer is not None else 1.0
         self.opt.step(grad_scale=scale)
         info["loss"] = loss.detach()
         return info
 
-    def _forward_backward(self, images, labels, accumulate):
+    def _forward_backward(self, images, labels, accumulate, next_images=None):
         self.opt.refresh_transposed_weights()
         self.student.train()
-        loss, info = self.forward_losses(images, labels, accumulate=accumulate)
+        loss, info = self.forward_losses(images, labels, accumulate=accumulate, next_images=next_images)
         self.opt.zero_grad()
         with ops.async_weight_grads():              # wgrad GEMMs trail the dgrad chain on a second stream; joined on exit
             loss.backward()

@@ -252,7 +252,6 @@ class BlockFn(torch.autograd.Function):
             ao, lse, cinv, cls_row = ops.attn_policy_fwd(qkv, policy, B, n, heads, scale, want_cls=want_cls)
         x2d = x.view(M, D)
         x1 = ops.linear_fwd(ao, projw, projb, epi=ops.EPI_BIAS_RESID, aux=x2d, a16=aoh)
-        del aoh
         z = torch.empty((M, hidden), dtype=torch.float32, device=x.device)
         if io:
             _, mean2, rstd2, ln2h = ops.layernorm_fwd_bf16(x1, cmap, n2w, n2b, M, D, eps, want_f32=False)
@@ -267,7 +266,7 @@ class BlockFn(torch.autograd.Function):
             y = ops.linear_fwd(h, fc2w, fc2b, epi=ops.EPI_BIAS_RESID, aux=x1)
         del ln2h, hh
         ctx.save_for_backward(x, n1w, qkvw, projw, n2w, fc1w, fc2w, mean1, rstd1, ln1, qkv, ao, lse, x1, mean2, rstd2, ln2, z, h,
-                              n1b, qkvb, projb, n2b, fc1b, fc2b)
+                              n1b, qkvb, projb, n2b, fc1b, fc2b, aoh)      # aoh: bf16 form of ao (bf16 attention only), proj's weight gradient
         ctx.policy = (policy, cinv)
         ctx.dims = (B, n, D, heads, scale)
         if cls_row is None:
@@ -296,7 +295,7 @@ class BlockFn(torch.autograd.Function):
         if ctx.composite:
             return BlockFn._backward_composite(ctx, gy)
         (x, n1w, qkvw, projw, n2w, fc1w, fc2w, mean1, rstd1, ln1, qkv, ao, lse, x1, mean2, rstd2, ln2, z, h,
-         n1b, qkvb, projb, n2b, fc1b, fc2b) = ctx.saved_tensors
+         n1b, qkvb, projb, n2b, fc1b, fc2b, aoh) = ctx.saved_tensors
         B, n, D, heads, scale = ctx.dims
         M = B * n
         dev = gy.device
@@ -312,7 +311,6 @@ class BlockFn(torch.autograd.Function):
         def xarg(t):      # a saved layer input is fp32, or bf16 only on the bf16 data path
             return (None, t) if t.dtype == torch.bfloat16 else (t, None)
         hx, h16 = xarg(h)
-        grads[11], grads[12] = ops.linear_param_grads(gy, hx, fc2w, fc2b, wants[11], wants[12], x16=h16)
         # bf16 data path: every gradient that feeds an input-gradient GEMM is also produced in bf16 by the kernel that computes it
         io = ops.bf16_io() and z.shape[1] % 32 == 0 and D % 32 == 0 and gy.is_cuda
         policy, cinv = ctx.policy
@@ -320,6 +318,9 @@ class BlockFn(torch.autograd.Function):
         gyh = ops.shadow_take(gy) if io else None
         if gyh is not None:
             gyh = gyh.view(M, D)
+        # with both operands at hand in bf16 the weight-gradient kernel reads them where they lie (token-major, no transposing pass); the
+        # bias gradient is then the sum of the bf16 gradient values, as under torch.autocast
+        grads[11], grads[12] = ops.linear_param_grads(gy, hx, fc2w, fc2b, wants[11], wants[12], x16=h16, dy16=gyh if h16 is not None else None)
         dzh = ops.bf16_buffer(M, z.shape[1], dev) if io else None
         l2x, l216 = xarg(ln2)
         # dz = (gy fc2w) * gelu'(z) feeds two bf16 GEMMs and nothing else: on the bf16 data path only its bf16 form is written (fc1's bias
@@ -337,7 +338,7 @@ class BlockFn(torch.autograd.Function):
         ops.layernorm_bwd(x1, cmap, dln2, n2w, mean2, rstd2, g1, gy, dn2w, dn2b, M, D, dx16=g1h)
         grads[7], grads[8] = (dn2w if wants[7] else None), (dn2b if wants[8] else None)
         # ---- attention branch ----
-        grads[5], grads[6] = ops.linear_param_grads(g1, ao, projw, projb, wants[5], wants[6])
+        grads[5], grads[6] = ops.linear_param_grads(g1, ao, projw, projb, wants[5], wants[6], x16=aoh, dy16=g1h if aoh is not None else None)
         dao = ops.linear_dgrad(g1, projw, a16=g1h)
         del g1h
         dqkvh = None

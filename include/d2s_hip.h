@@ -71,7 +71,9 @@ int d2s_linear_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, f
 /* mode 2, bf16 data path: the same with the layer input available in bf16 only (x_bf16 [tokens][n_in], what the forward saved instead of
  * the fp32 activation).  dy is fp32 - its exact column sums are the bias gradient - or, where the kernel that produced the gradient wrote
  * bf16 only, dy_bf16 [tokens][n_out] (dy may then be NULL; the bias gradient is the fp32 sum of the bf16 values, as under torch.autocast).
- * Workspace: d2s_linear_wgrad_workspace_bytes(.., 2). */
+ * Both may be given (dy_bf16 = dy rounded to bf16): with tokens % 64 == 0 and an output of 256x256 tiles the matrix kernel then reads
+ * dy_bf16 and x_bf16 token-major as they lie (no transposing pass), the bias gradient stays the exact column sum of dy, and the result
+ * is bit-identical to the dy-only call.  Workspace: d2s_linear_wgrad_workspace_bytes(.., 2). */
 int d2s_linear_wgrad_f32_bf16x(const float* dy, const void* dy_bf16, long lddy, const void* x_bf16, long ldx, float* dW, long lddw, float* db,
                                int tokens, int n_out, int n_in, int accumulate, void* workspace, size_t workspace_bytes, d2s_stream_t stream);
 /* dst[C][R] = src[R][C]^T: a k-contiguous copy W^T of an nn.Linear weight, so that autograd's dx = dy W (vit_models/dynamic_vit.py:169-175

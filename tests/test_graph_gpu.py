@@ -190,3 +190,31 @@ def test_composite_block_calls_are_bit_identical_to_the_per_op_sequence(name, mo
         assert all(torch.equal(p, q) for p, q in zip(a[1], b[1])), i
         assert torch.equal(a[2], b[2]), f"step {i}: gradients differ"
         assert torch.equal(a[3], b[3]), f"step {i}: parameters differ"
+
+
+def test_teacher_lookahead_is_bit_identical_and_survives_a_wrong_announcement():
+    """TrainStep(images, labels, next_images): the frozen teacher's forward for the next batch is issued one step early, on the teacher
+    stream, beside this step's backward.  Same kernels on the same inputs, so every step is bit-identical to the plain one - also when
+    the batch that arrives is not the one that was announced (its early teacher pass is dropped and recomputed)."""
+    from d2s.engine import TrainStep
+    dev = torch.device("cuda:0")
+    case = cases.MODEL_CASES["micro2"]
+    plain, ahead = [TrainStep(*build_models(case, dev)[:2], make_args(case["cfg"]), graph=False, warmup_steps=0) for _ in range(2)]
+    data = _batches(case, 5, dev)
+
+    class Both:                                                    # _same_step calls (x, y); this one also announces the next batch
+        def __init__(self, ts):
+            self.ts, self.nxt = ts, None
+        def __call__(self, x, y):
+            return self.ts(x, y, self.nxt)
+        def __getattr__(self, k):
+            return getattr(self.ts, k)
+    both = Both(ahead)
+    used = []
+    for i, (x, y) in enumerate(data):
+        both.nxt = data[i + 1][0] if i + 1 < len(data) and i != 2 else (data[0][0] if i == 2 else None)     # step 2 announces the WRONG batch
+        had = ahead._ahead is not None and ahead._ahead["key"] == ahead._batch_key(x)
+        _same_step(plain, both, x, y, f"step {i}")
+        used.append(had)
+    assert used == [False, True, True, False, True], used
+    assert ahead._ahead is None

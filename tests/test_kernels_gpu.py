@@ -545,10 +545,13 @@ def test_linear_wgrad_bf16_mode(ops, tokens, n_out, n_in):
         ops.set_gemm_mode(ops.GEMM_EXACT)
 
 
-@pytest.mark.parametrize("tokens,n_out,n_in", [(197 * 8, 384, 1536), (5000, 768, 768), (1001, 96, 200)])
+@pytest.mark.parametrize("tokens,n_out,n_in", [(197 * 8, 384, 1536), (5000, 768, 768), (1001, 96, 200),
+                                                (4096, 768, 1024), (2304, 1160, 768), (173 * 64, 2304, 768), (8192, 512, 264)])
 def test_linear_wgrad_bf16_input(ops, tokens, n_out, n_in):
     """d2s_linear_wgrad_f32_bf16x: with the layer input handed over in bf16 (what the bf16 data path saves) the weight and bias gradients
-    are bit-identical to the fp32-input call, which rounds the same values itself."""
+    are bit-identical to the fp32-input call, which rounds the same values itself.  The last four shapes (tokens a multiple of 64, outputs
+    that fill 256x256 tiles) take the token-major matrix kernel when both operands come in bf16 (no transposing pass; csrc/gemm_split.hip
+    gemm_bf16_dma_kernel<.., TOK>): same products in the same order, so still bit-identical - ragged tile edges included."""
     g = torch.Generator().manual_seed(tokens)
     dy = torch.randn(tokens, n_out, generator=g).to(_dev())
     x = torch.randn(tokens, n_in, generator=g).to(_dev())
@@ -566,6 +569,11 @@ def test_linear_wgrad_bf16_input(ops, tokens, n_out, n_in):
         assert torch.equal(dW3, dW1)
         ref_b = dy.bfloat16().double().sum(0)
         assert (db3.double() - ref_b).abs().max() <= 1e-5 * math.sqrt(tokens) * 10
+        # both forms of the gradient (fp32 + its bf16 rounding, as the LayerNorm backward hands them over): weights from the bf16 operands,
+        # bias from the fp32 one - bit-identical to the fp32-only call
+        dW4, db4 = torch.empty(n_out, n_in, device=_dev()), torch.empty(n_out, device=_dev())
+        ops.linear_wgrad(dy, None, dW4, db=db4, x16=x.bfloat16(), dy16=dy.bfloat16())
+        assert torch.equal(dW4, dW1) and torch.equal(db4, db1)
     finally:
         ops.set_gemm_mode(ops.GEMM_EXACT)
 
