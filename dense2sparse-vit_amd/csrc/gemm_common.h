@@ -15,6 +15,9 @@ enum Epi : int {
     EPI_MUL_RELU_MASK = 6, // C = acc * (aux[m][n] > 0)       (aux = saved ReLU output)
     EPI_BIAS_ROWADD = 7,   // C = acc + bias[n] + aux[(m % aux_rows)][n]  (patch embed: + pos_embed rows)
     EPI_ACCUM = 8,         // C += acc
+    // C-ABI codes of d2s_gemm_f32_bf16io only (mapped to the two kinds above + GemmArgs::aux_bf16): the saved GELU pre-activation in bf16
+    EPI_BIAS_GELU_Z16 = 9,      // as EPI_BIAS_GELU, aux_out is bf16 [M][ldc]
+    EPI_MUL_GELU_GRAD_Z16 = 10, // as EPI_MUL_GELU_GRAD, aux is bf16 [M][ldaux]
 };
 
 struct GemmArgs {
@@ -37,7 +40,10 @@ struct GemmArgs {
     // c16 = where to put a bf16 copy of the result, dense [M][N] (N % 32 == 0): the next GEMM's a16
     const void* a16; void* c16;
     const void* b16;   // bf16 mode: the B operand already in bf16, [N][K] k-contiguous whatever the layout (a cached weight, or W^T for dgrad)
+    int aux_bf16;      // bf16 mode: aux_out (EPI_BIAS_GELU) / aux (EPI_MUL_GELU_GRAD) point at bf16, not float
 };
+
+typedef __bf16 bf16x4_epi __attribute__((ext_vector_type(4)));
 
 template <int EPI, int MT, int NT>
 __device__ __forceinline__ void store_tile_out(const GemmArgs& p, float* __restrict__ Cb, const f32x16 (&acc)[MT][NT], int mbase,
@@ -64,11 +70,13 @@ __device__ __forceinline__ void store_tile_out(const GemmArgs& p, float* __restr
                 if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
                 if (EPI == EPI_BIAS_GELU) {
                     v += bias;
-                    if (p.aux_out) p.aux_out[(long)m * p.ldc + n] = v;
+                    if (p.aux_out && p.aux_bf16) reinterpret_cast<__bf16*>(p.aux_out)[(long)m * p.ldc + n] = (__bf16)v;
+                    else if (p.aux_out) p.aux_out[(long)m * p.ldc + n] = v;
                     v = gelu_erf(v);
                 }
                 if (EPI == EPI_BIAS_RESID) v += bias + p.aux[(long)m * p.ldaux + n];
-                if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(p.aux[(long)m * p.ldaux + n]);
+                if (EPI == EPI_MUL_GELU_GRAD)
+                    v *= gelu_erf_grad(p.aux_bf16 ? (float)reinterpret_cast<const __bf16*>(p.aux)[(long)m * p.ldaux + n] : p.aux[(long)m * p.ldaux + n]);
                 if (EPI == EPI_MUL_RELU_MASK) v = p.aux[(long)m * p.ldaux + n] > 0.f ? v : 0.f;
                 if (EPI == EPI_BIAS_ROWADD) v += bias + p.aux[(long)(m % p.aux_rows) * p.ldaux + n];
                 if (EPI == EPI_ACCUM) v += *cp;
@@ -125,12 +133,26 @@ __device__ __forceinline__ void store_tile_out_lds(const GemmArgs& p, float* __r
                     for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                 }
                 if (EPI == EPI_BIAS_GELU) {
-                    if (p.aux_out) *reinterpret_cast<f32x4*>(p.aux_out + (long)m * p.ldc + n) = v;
+                    if (p.aux_out && p.aux_bf16) {
+                        bf16x4_epi zh;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) zh[j] = (__bf16)v[j];
+                        *reinterpret_cast<bf16x4_epi*>(reinterpret_cast<__bf16*>(p.aux_out) + (long)m * p.ldc + n) = zh;
+                    } else if (p.aux_out) {
+                        *reinterpret_cast<f32x4*>(p.aux_out + (long)m * p.ldc + n) = v;
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
                 }
                 if (EPI == EPI_BIAS_RESID || EPI == EPI_MUL_GELU_GRAD || EPI == EPI_MUL_RELU_MASK) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + (long)m * p.ldaux + n);
+                    f32x4 a;
+                    if (EPI == EPI_MUL_GELU_GRAD && p.aux_bf16) {
+                        const bf16x4_epi zh = *reinterpret_cast<const bf16x4_epi*>(reinterpret_cast<const __bf16*>(p.aux) + (long)m * p.ldaux + n);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = (float)zh[j];
+                    } else {
+                        a = *reinterpret_cast<const f32x4*>(p.aux + (long)m * p.ldaux + n);
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (EPI == EPI_BIAS_RESID) v[j] += a[j];

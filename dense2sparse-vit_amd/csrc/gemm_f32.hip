@@ -937,10 +937,21 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
         if ((reinterpret_cast<uintptr_t>(a16) & 7) != 0) return D2S_ERR_ARG;
     }
     if ((a16 && layout != 2 && (K % 32 != 0 || !aligned16(a16))) || (c16 && (N % 32 != 0 || !aligned16(c16)))) return D2S_ERR_ARG;
+    int aux_bf16 = 0;       // bf16 data path: the GELU pre-activation saved / read in bf16 (d2s_gemm_f32_bf16io, codes 9 / 10)
+    if (epilogue == EPI_BIAS_GELU_Z16 || epilogue == EPI_MUL_GELU_GRAD_Z16) {
+        const float* z = epilogue == EPI_BIAS_GELU_Z16 ? aux_out : aux;
+        if (mode != 2 || layout == 2 || !z || (reinterpret_cast<uintptr_t>(z) & 7) || N % 4 != 0 || (epilogue == EPI_MUL_GELU_GRAD_Z16 && ldaux % 4 != 0) ||
+            (epilogue == EPI_BIAS_GELU_Z16 && ldc % 4 != 0))
+            return D2S_ERR_ARG;
+        aux_bf16 = 1;
+        epilogue = epilogue == EPI_BIAS_GELU_Z16 ? EPI_BIAS_GELU : EPI_MUL_GELU_GRAD;
+    }
+    if (epilogue < EPI_NONE || epilogue > EPI_ACCUM) return D2S_ERR_ARG;
     if ((epilogue == EPI_BIAS_RESID || epilogue == EPI_MUL_GELU_GRAD || epilogue == EPI_MUL_RELU_MASK ||
          epilogue == EPI_BIAS_ROWADD) && !aux)
         return D2S_ERR_ARG;
     GemmArgs p;
+    p.aux_bf16 = aux_bf16;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux = aux; p.aux_out = aux_out;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
     p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.aux_rows = aux_rows > 0 ? aux_rows : 1;

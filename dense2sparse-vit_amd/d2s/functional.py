@@ -252,7 +252,8 @@ class BlockFn(torch.autograd.Function):
             ao, lse, cinv, cls_row = ops.attn_policy_fwd(qkv, policy, B, n, heads, scale, want_cls=want_cls)
         x2d = x.view(M, D)
         x1 = ops.linear_fwd(ao, projw, projb, epi=ops.EPI_BIAS_RESID, aux=x2d, a16=aoh)
-        z = torch.empty((M, hidden), dtype=torch.float32, device=x.device)
+        # GELU pre-activation for the backward: fp32, or bf16 on the bf16 data path (what autocast keeps: fc1's output is bf16 there)
+        z = torch.empty((M, hidden), dtype=torch.bfloat16 if (io and ops._BF16_PREACT) else torch.float32, device=x.device)
         if io:
             _, mean2, rstd2, ln2h = ops.layernorm_fwd_bf16(x1, cmap, n2w, n2b, M, D, eps, want_f32=False)
             ln2 = ln2h

@@ -11,11 +11,13 @@ from . import lib
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_GELU, EPI_BIAS_RESID = 0, 1, 2, 3, 4
 EPI_MUL_GELU_GRAD, EPI_MUL_RELU_MASK, EPI_BIAS_ROWADD, EPI_ACCUM = 5, 6, 7, 8
+EPI_BIAS_GELU_Z16, EPI_MUL_GELU_GRAD_Z16 = 9, 10      # d2s_gemm_f32_bf16io only: the saved GELU pre-activation in bf16 (chosen by gemm() from the tensor's dtype)
 NT, NN, TN = 0, 1, 2
 
 _ws = {}
 _WS_NEED = {}       # (layout, M, N, K, mode) -> workspace bytes of d2s_gemm_f32 (a pure function of its arguments)
 _BF16_ATTENTION = os.environ.get("D2S_BF16_ATTENTION", "1") != "0"
+_BF16_PREACT = os.environ.get("D2S_BF16_PREACT", "1") != "0"      # bf16 data path: fc1's pre-activation is saved in bf16 (0: fp32, A/B)
 
 
 def workspace(nbytes, device):
@@ -163,6 +165,10 @@ def gemm(layout, A, lda, B, ldb, C, ldc, M, N, K, epi=EPI_NONE, bias=None, aux=N
         need = _WS_NEED[qk] = lib.query("d2s_gemm_f32_workspace_bytes", layout, M, N, K, mode)
     dev = C.device if C is not None else c16.device
     ws = workspace(need, dev) if need else None
+    z16 = (aux_out if epi == EPI_BIAS_GELU else aux if epi == EPI_MUL_GELU_GRAD else None)
+    if z16 is not None and z16.dtype == torch.bfloat16:      # bf16 data path: the GELU pre-activation is kept in bf16 (as under autocast)
+        assert a16 is not None or c16 is not None or b16 is not None, "a bf16 pre-activation exists on the bf16 data path only"
+        epi = EPI_BIAS_GELU_Z16 if epi == EPI_BIAS_GELU else EPI_MUL_GELU_GRAD_Z16
     if a16 is not None or c16 is not None or b16 is not None:
         assert mode == GEMM_BF16 and not accumulate and remap_rows == 0 and aux_rows == 0
         assert b16 is None or (b16.dtype == torch.bfloat16 and b16.is_contiguous() and tuple(b16.shape) == (N, K)), "b16 must be dense bf16 [N, K]"

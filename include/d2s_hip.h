@@ -54,7 +54,9 @@ int d2s_gemm_f32(int layout, const float* A, long lda, const float* B, long ldb,
  * 218-231): the same GEMM with bf16 side channels.  a_bf16 (optional): the A operand already rounded to bf16, dense [M][K], K % 32 == 0 -
  * the call skips its conversion pass over A (A, if given, must hold the same values; it may be NULL).  c_bf16 (optional): a dense [M][N]
  * bf16 copy of the result, N % 32 == 0, written by the same epilogue - the a_bf16 of the next GEMM (C may then be NULL).  Producers of
- * a_bf16 other than a GEMM: d2s_layernorm_fwd_bf16out, d2s_attn_fwd_bf16_bf16out.  NT / NN layouts; workspace as d2s_gemm_f32 in mode 2. */
+ * a_bf16 other than a GEMM: d2s_layernorm_fwd_bf16out, d2s_attn_fwd_bf16_bf16out.  NT / NN layouts; workspace as d2s_gemm_f32 in mode 2.
+ * Two more epilogue codes, this entry only: 9 = 3 with aux_out pointing at bf16 [M][ldc] (fc1's pre-activation kept in bf16 for the
+ * backward, as autocast keeps it), 10 = 5 with aux pointing at bf16 [M][ldaux] (the input gradient of fc2 reading it back). */
 int d2s_gemm_f32_bf16io(int layout, const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
                         int epilogue, const float* bias, const float* aux, long ldaux, float* aux_out, const void* a_bf16, const void* b_bf16,
                         void* c_bf16, void* workspace, size_t workspace_bytes, d2s_stream_t stream);

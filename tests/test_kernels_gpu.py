@@ -377,6 +377,17 @@ def test_gemm_bf16_io(ops, M, N, K):
         np.testing.assert_allclose(z.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
         np.testing.assert_allclose(h.cpu().numpy(), F.gelu(ref).numpy(), rtol=1e-4, atol=2e-5)
         assert torch.equal(c16, h.bfloat16())
+        # the pre-activation kept in bf16 (epilogue codes 9 / 10, picked from the tensor's dtype): the same values rounded once, the same
+        # activation; fc2's input gradient reading it back equals the fp32-aux call on the rounded values
+        z16 = torch.empty((M, N), dtype=torch.bfloat16, device=_dev())
+        h2 = ops.linear_fwd(xd, wd, bd, epi=ops.EPI_BIAS_GELU, aux_out=z16, a16=x16, c16=c16b)
+        assert torch.equal(z16, z.bfloat16()) and torch.equal(h2, h) and torch.equal(c16b, c16)
+        if N % 32 == 0:
+            gyd = _rand("igy", (M, K), seed=M + 7).to(_dev())
+            w2 = _rand("iw2", (K, N), 0.05, seed=K).to(_dev())                    # fc2.weight [D, hidden]: dz = (gy @ w2) * gelu'(z)
+            dz_a = ops.linear_dgrad(gyd, w2, epi=ops.EPI_MUL_GELU_GRAD, aux=z16.float(), a16=gyd.bfloat16())
+            dz_b = ops.linear_dgrad(gyd, w2, epi=ops.EPI_MUL_GELU_GRAD, aux=z16, a16=gyd.bfloat16())
+            assert torch.equal(dz_a, dz_b)
         # the weight handed over in bf16 (d2s_convert_bf16 once, instead of a conversion inside every call): identical result
         from d2s import lib
         w16 = torch.empty((N, K), dtype=torch.bfloat16, device=_dev())
