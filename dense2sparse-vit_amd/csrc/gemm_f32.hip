@@ -836,7 +836,7 @@ size_t split_tn_pieces_bytes(int split, int M, int N, int K);
 int split_tn_colsum_partials(int K);
 bool split_tn_use_dma(int M, int N, int K);
 int split_tn_dma_slices(int M, int N, int K);
-int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_ws, float* colsum_part, hipStream_t stream);
+int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_ws, float* colsum_part, hipStream_t stream, int* colsum_parts);
 }
 // Workgroups the wgrad launch aims for (tiles x K slices, rounded down).  Run alone, exactly 2 per CU is best (tools/gemm_bench.py,
 // D2S_SPLITK_TARGET sweep in round 1: 512 beats 768 / 1024 by 4-15 % - fewer, longer K slices mean less slab traffic for the ordered
@@ -991,14 +991,15 @@ static int gemm_impl(int layout, const float* A, long lda, const float* B, long 
         p.slab_stride = (long)M * N;
         p.remap_rows_per_img = 0;
         float* cs_part = colsum_out ? reinterpret_cast<float*>(wsb + slab_bytes + piece_bytes) : nullptr;
-        int rc = launch_split_gemm_tn(p, 1, slices, wsb + slab_bytes, cs_part, stream);
+        int cs_parts = 0;
+        int rc = launch_split_gemm_tn(p, 1, slices, wsb + slab_bytes, cs_part, stream, &cs_parts);
         if (rc != D2S_OK) return rc;
         const long total = (long)M * N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                            reinterpret_cast<const float*>(wsb), C, ldc, M, N, slices, (long)M * N, accumulate,
                            static_cast<const float*>(nullptr), static_cast<float*>(nullptr));
         if (colsum_out)   // ordered fold of the per-64-token partials that the split pass of dy produced (exact fp32)
-            hipLaunchKernelGGL(colsum_fold_wide_kernel, dim3((M + 15) / 16), dim3(1024), 0, stream, cs_part, M, split_tn_colsum_partials(K),
+            hipLaunchKernelGGL(colsum_fold_wide_kernel, dim3((M + 15) / 16), dim3(1024), 0, stream, cs_part, M, cs_parts,
                                colsum_out, accumulate);
         return d2s_check_launch();
     }

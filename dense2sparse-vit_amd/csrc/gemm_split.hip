@@ -558,6 +558,20 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm_bf16_dma_kernel(GemmArgs p,
     // the next step's fragments - across a slab boundary: wait + barrier, request slab kt + NS into the buffer just drained - | 7 MFMAs.
 #define D2S_PIN() __builtin_amdgcn_sched_barrier(0)
     bf16x8 fa[2][4], fb[2][2];
+    // token-major form, bias gradient: the workgroups of column tile 0 also sum the dy fragments they hold anyway (wave wn takes K step wn of
+    // every slab, so the 32 conversions + adds per slab and wave sit beside 32 MFMAs); one partial row per K slice goes to p.colsum
+    const bool do_cs = TOK && p.colsum != nullptr && col0 == 0;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    auto cs_add = [&](const bf16x8 (&a)[4], int ks) {
+        if constexpr (TOK) {
+            if (do_cs && wn == ks) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) cs[t] += (float)a[t][j];
+            }
+        }
+    };
     // steps 0 .. KS-2 of the slab in `st` (fragments of step 0 in set 0 on entry; on exit set 1 holds step KS-1)
     auto inner_steps = [&](const unsigned char* st) {
 #pragma unroll
@@ -567,6 +581,7 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm_bf16_dma_kernel(GemmArgs p,
             rd(st, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
             D2S_PIN();
             mm_tail(fa[ks & 1], fb[ks & 1]);
+            cs_add(fa[ks & 1], ks);
             D2S_PIN();
         }
     };
@@ -588,6 +603,7 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm_bf16_dma_kernel(GemmArgs p,
         rd(smem_raw + buf * STAGE, 0, fa[0], fb[0]);
         D2S_PIN();
         mm_tail(fa[1], fb[1]);
+        cs_add(fa[1], KS - 1);
         D2S_PIN();
     }
     for (; kt + 1 < nk; ++kt) {           // drain: nothing left to request
@@ -599,14 +615,34 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm_bf16_dma_kernel(GemmArgs p,
         rd(smem_raw + buf * STAGE, 0, fa[0], fb[0]);
         D2S_PIN();
         mm_tail(fa[1], fb[1]);
+        cs_add(fa[1], KS - 1);
         D2S_PIN();
     }
     inner_steps(smem_raw + buf * STAGE);
     mm_head(fa[1], fb[1]);
     mm_tail(fa[1], fb[1]);
+    cs_add(fa[1], KS - 1);
 #undef D2S_PIN
     // every wave is done with the operand images: reuse the LDS for the epilogue's wave-private staging (raw barrier: nothing to drain)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (TOK) {
+        if (do_cs) {      // workgroup-uniform.  Exchange area past the epilogue's staging buffers: [wm][wn][t][lane] floats at byte 64 K
+            float* csx = reinterpret_cast<float*>(smem_raw + 65536);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) csx[((wm * 4 + wn) * 4 + t) * 64 + lane] = cs[t];
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (wn == 0 && lane < 32) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) v += csx[((wm * 4 + w) * 4 + t) * 64 + lane] + csx[((wm * 4 + w) * 4 + t) * 64 + 32 + lane];
+                    const int row = row0 + wm * 128 + t * 32 + lane;
+                    if (row < p.M) p.colsum[(long)slice * p.M + row] = v;
+                }
+            }
+        }
+    }
     float* stage = reinterpret_cast<float*>(smem_raw) + wave * epi_stage_floats(2);
     store_tile_dispatch_lds<4, 2, true>(p.epi, p, p.C ? p.C + (long)slice * p.slab_stride : p.C, acc, row0 + wm * 128, col0 + wn * 64, lane, stage);
     // the next tile's DMA overwrites the staging area: wait for every wave's staging reads (not for the global stores)
@@ -794,7 +830,8 @@ __global__ __launch_bounds__(256) void colsum_tok_kernel(const ST* __restrict__ 
 // colsum_part (optional, [split_tn_colsum_partials(K)][M] floats): per-64-token partial column sums of A (= dy), produced by the split
 // pass that reads dy anyway; the caller folds them in order into the bias gradient.
 int split_tn_colsum_partials(int K) { return tn_kp(K) / 64; }
-int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_ws, float* colsum_part, hipStream_t stream) {
+int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_ws, float* colsum_part, hipStream_t stream, int* colsum_parts) {
+    if (colsum_parts) *colsum_parts = split_tn_colsum_partials(p.K);      // partial rows written to colsum_part (the caller folds that many)
     const int Kp = tn_kp(p.K);
     if (split != 1) return D2S_ERR_ARG;
     if ((long)p.M * Kp * 2 >= (1L << 32) || (long)p.N * Kp * 2 >= (1L << 32)) return D2S_ERR_ARG;
@@ -807,11 +844,16 @@ int launch_split_gemm_tn(const GemmArgs& p, int split, int slices, void* pieces_
     if (tok_env && p.b16 && p.a16 && p.K % 64 == 0 && p.M % 8 == 0 && p.N % 8 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 &&
         (reinterpret_cast<uintptr_t>(p.b16) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.a16) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && split_tn_use_dma(p.M, p.N, p.K) &&
         epilogue_vec_ok(p) && p.slab_stride % 4 == 0 && p.k_per_slice % 64 == 0 && (long)p.K * p.lda * 2 < (1L << 32) && (long)p.K * p.ldb * 2 < (1L << 32)) {
+        static const int cs_env = [] { const char* e = getenv("D2S_TN_COLSUM_INKERNEL"); return e ? atoi(e) : 1; }();
+        GemmArgs pt = p;
+        pt.colsum = nullptr;
         if (colsum_part && p.A)       // the fp32 gradient exists too: the bias gradient stays its exact column sum
             hipLaunchKernelGGL(colsum_tok_kernel<float>, dim3((p.M + 255) / 256, p.K / 64), block, 0, stream, p.A, p.lda, p.M, colsum_part);
-        else if (colsum_part)
+        else if (colsum_part && cs_env && colsum_parts) {      // bf16-only gradient: summed by the matrix kernel itself, one partial row per K slice
+            pt.colsum = colsum_part;
+            *colsum_parts = slices;
+        } else if (colsum_part)
             hipLaunchKernelGGL(colsum_tok_kernel<__bf16>, dim3((p.M + 255) / 256, p.K / 64), block, 0, stream, static_cast<const __bf16*>(p.b16), p.lda, p.M, colsum_part);
-        GemmArgs pt = p;
         pt.vec_epilogue = 1;
         pt.a16 = nullptr; pt.c16 = nullptr; pt.b16 = nullptr;
         PieceArgs qt{static_cast<const __bf16*>(p.b16), static_cast<const __bf16*>(p.a16), p.K};
