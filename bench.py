@@ -284,8 +284,8 @@ def cpu_baseline(keep, batch=32, warm=2, steps=10):
                 sample=f"{steps} full train steps of the CPU oracle at batch {batch} (same model/config, fp32), after {warm} warm-up; {dt:.1f} s")
 
 
-PMC_FILE = "r03_g_pmc_traffic.json"
-PMC_FILE_C5 = "r03_g_pmc_traffic_c5.json"      # the same two passes over `bench.py --config c5`
+PMC_FILE = "r03_m_pmc_traffic.json"
+PMC_FILE_C5 = "r03_m_pmc_traffic_c5.json"      # the same two passes over `bench.py --config c5`
 
 
 def pmc_traffic(kernel_prefix, pmc_file=None):
