@@ -593,6 +593,8 @@ def main():
                 for ms, lay, M, N, K, n, us, tf in sorted(rows, reverse=True):
                     f.write(f"{lay} {M:6d} {N:5d} {K:6d} {n:5.1f} {us:8.1f} {tf:7.1f} {ms:7.3f}\n")
         line["c_abi_calls_per_step"] = round(timer.launch_calls / args.steps, 1)
+        # side streams are chosen so that they sit on another hardware queue than the main stream (d2s.ops.concurrent_stream): purpose, candidates tried, verified
+        line["side_streams"] = [{"for": p, "candidates_tried": n, "runs_beside_main": ok} for p, n, ok in ops.stream_picks]
         sc = summ.get(("scatter_unpack", ""))
         if sc:
             gbs = sc["work"] / (sc["ms"] * 1e-3) / 1e9
@@ -627,6 +629,8 @@ def main():
             c = ts.reducer.comm_summary(args.steps * (2 if (instr_elapsed is not None and not in_region) else 1))   # both passes all-reduce
             if c:
                 line["comm"] = c
+                # did the stream the step is issued on share a hardware queue with the process group's RCCL stream, and was the step moved
+                line["comm"]["rccl_stream_probe"] = ts.pg_probe
         if n_gpus == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle (bounded sample)")
             line["cpu_baseline"] = cpu_baseline(args.keep)

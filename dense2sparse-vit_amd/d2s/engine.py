@@ -212,7 +212,8 @@ class GradReducer:
         self.arena, self.group = arena, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.stream = torch.cuda.Stream() if arena.params.is_cuda else None
+        # its waits on the weight-gradient stream sit in its hardware queue: on the main stream's queue they would stall the backward itself
+        self.stream = ops.concurrent_stream([torch.cuda.current_stream()], "gradient exchange") if arena.params.is_cuda else None
         if bucket_mb is None:
             bucket_mb = float(os.environ.get("D2S_DDP_BUCKET_MB", "16"))
         self.collective = collective or os.environ.get("D2S_DDP_COLLECTIVE", "allreduce")
@@ -372,7 +373,8 @@ class TrainStep:
         # the frozen teacher's forward runs on a second HIP stream beside the student's forward (independent until the losses):
         # +2.6 % images/s, identical losses (profiles/r02_f_teacher_stream_ab.txt).  D2S_TEACHER_STREAM=0 serialises them.
         two = os.environ.get("D2S_TEACHER_STREAM", "1") == "1" and self.arena.params.is_cuda
-        self._teacher_stream = torch.cuda.Stream() if two else None
+        # chosen, not just created: it must sit on another hardware queue than the stream the step is issued on (ops.concurrent_stream)
+        self._teacher_stream = ops.concurrent_stream([torch.cuda.current_stream()], "teacher forward") if two else None
         if graph is None:
             graph = {"0": False, "1": True, "auto": "auto"}[os.environ.get("D2S_STEP_GRAPH", "0")]
         self.graph = None if graph == "auto" else bool(graph)      # True | False | None (auto: small per-rank batches only)
@@ -380,6 +382,9 @@ class TrainStep:
         self._graphs = {}                   # key -> entry (see _graph_step)
         self._capture_stream = None
         self._ahead = None                  # teacher outputs of the next batch, issued one step early (_teacher_ahead)
+        self._steps_seen = 0
+        self._step_on_side = False          # the step is issued on a stream of its own choice (see _place_beside_process_group)
+        self.pg_probe = None
         self.last_step_captured = False     # diagnostic: did the last call replay a graph
         self.set_epoch(0)
 
@@ -458,7 +463,16 @@ class TrainStep:
         forward for it is then issued during this step (see _teacher_ahead) - every step still runs exactly one teacher forward, the
         results are bit-identical, and a following call with any other batch simply recomputes.  Eager steps only."""
         self.arena.check_alias()
-        if self.graph is False or not images.is_cuda:
+        if images.is_cuda and self._steps_seen == 0 and self.reducer is not None:
+            self._place_beside_process_group()
+        if images.is_cuda and self.graph is False and self._steps_seen in (1, 3):
+            # the side streams were picked before anything else had run; an RCCL communicator (and whatever else creates streams late)
+            # can have moved onto their hardware queues since: verify once the first step(s) are behind us
+            main = self._capture_stream if self._step_on_side else torch.cuda.current_stream()
+            self._teacher_stream = ops.recheck_stream(self._teacher_stream, [main], "teacher forward")
+            ops.recheck_weight_grad_stream([main])
+        self._steps_seen += 1
+        if (self.graph is False and not self._step_on_side) or not images.is_cuda:
             return self._eager_step(images, labels, next_images)
         # Graph-capable mode: EVERY step - the eager warm-up steps, the capture, the replays, and steps of shapes that stay eager - is
         # issued on one side stream of this TrainStep.  Autograd pins a parameter's AccumulateGrad node to the stream of the forward that
@@ -471,7 +485,7 @@ class TrainStep:
         side = self._capture_stream
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            info = self._graph_step(images, labels) if self._use_graph(images) else self._eager_step(images, labels)
+            info = self._graph_step(images, labels) if self._use_graph(images) else self._eager_step(images, labels, next_images)
         cur.wait_stream(side)
         if not self.last_step_captured:
             for v in info.values():            # allocated on the side stream, consumed (and freed) by the caller on its own stream
@@ -479,6 +493,32 @@ class TrainStep:
                     if torch.is_tensor(t) and t.is_cuda:
                         t.record_stream(cur)
         return info
+
+    def _place_beside_process_group(self):
+        """First call of a data-parallel TrainStep: make sure the stream the step is issued on does not share a hardware queue with the
+        process group's RCCL stream (ops.pg_stream_shares_queue).  If it does on ANY rank, every rank probes the same three candidate
+        streams (the probes are collectives), and a rank whose stream collided moves its steps to the first candidate that does not -
+        issued there the way the graph-capable mode issues them, the caller's stream waiting at both ends."""
+        if not (dist.is_initialized() and dist.get_backend(self.reducer.group) == "nccl") or self.graph is not False:
+            return
+        cur = torch.cuda.current_stream()
+        bad = ops.pg_stream_shares_queue(cur, self.reducer.group)
+        flag = torch.tensor([1.0 if bad else 0.0], device=self.arena.params.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.reducer.group)
+        self.pg_probe = {"caller_stream_shares_rccl_queue": bool(bad), "moved": False}
+        if float(flag.item()) == 0.0:
+            return
+        chosen = None
+        for _ in range(3):
+            cand = torch.cuda.Stream()
+            if not ops.pg_stream_shares_queue(cand, self.reducer.group) and chosen is None:
+                chosen = cand
+        if bad and chosen is not None:
+            self._capture_stream, self._step_on_side = chosen, True
+            self._teacher_stream = ops.recheck_stream(self._teacher_stream, [chosen], "teacher forward")
+            self.reducer.stream = ops.recheck_stream(self.reducer.stream, [chosen], "gradient exchange")
+            ops.recheck_weight_grad_stream([chosen])
+            self.pg_probe["moved"] = True
 
     def _eager_step(self, images, labels, next_images=None):
         self.last_step_captured = False

@@ -334,6 +334,95 @@ def linear_wgrad(dy, x, dW, accumulate=False, db=None, x16=None, dy16=None):
 # one, so they fill the CUs that the dgrad / attention kernels of the following layers leave idle in their tails; the caller joins the
 # stream before anything reads the gradients (join_weight_grads).  Outside that block - any caller that runs loss.backward() itself and
 # then reads .grad on the current stream - everything stays on the current stream.
+# HIP multiplexes a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4), and two streams that share a queue run
+# their kernels strictly one after the other.  Which queue a stream gets depends on what else created streams before it: with an RCCL
+# process group alive the teacher stream of d2s.engine landed on the main stream's queue and the teacher / student overlap was gone
+# (-5 % on the step, profiles/r03_o_stream_queue_collision.txt).  So a side stream is CHOSEN: candidates from torch's pool are kept only if a
+# pair of spin kernels shows that they really run beside every stream they are meant to overlap with.
+_STREAM_CHECK = os.environ.get("D2S_STREAM_CHECK", "1") != "0"
+stream_picks = []          # diagnostic: (purpose, candidates tried, verified concurrent)
+
+
+def _streams_overlap(a, b, cycles=3000000):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for st in (a, b):                         # first use of a stream sets things up lazily: keep that out of the measurement
+        with torch.cuda.stream(st):
+            torch.cuda._sleep(1000)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        ev[0].record()
+        torch.cuda._sleep(cycles)
+        ev[1].record()
+    with torch.cuda.stream(b):
+        ev[2].record()
+        torch.cuda._sleep(cycles)
+        ev[3].record()
+    torch.cuda.synchronize()
+    single = ev[0].elapsed_time(ev[1])
+    return ev[0].elapsed_time(ev[3]) < 1.6 * single      # one queue: the second spin starts when the first has ended (2x)
+
+
+def concurrent_stream(beside, purpose="", tries=12):
+    """A torch.cuda.Stream whose kernels run concurrently with those of every stream in `beside` (verified on the device), or - if no
+    candidate passes - the last candidate (the step is then correct but loses that overlap; stream_picks records it)."""
+    cand = torch.cuda.Stream()
+    if not _STREAM_CHECK:
+        return cand
+    kept = []                  # hold the rejected candidates while searching: the pool hands out its 32 streams round-robin
+    for n in range(1, tries + 1):
+        if all(_streams_overlap(o, cand) for o in beside):
+            stream_picks.append((purpose, n, True))
+            return cand
+        kept.append(cand)
+        cand = torch.cuda.Stream()
+    stream_picks.append((purpose, tries, False))
+    return cand
+
+
+def recheck_stream(stream, beside, purpose):
+    """`stream` if it still runs beside every stream in `beside`, else a replacement that does.  The queue a stream sits on can end up
+    shared AFTER it was picked (an RCCL communicator sets itself up at its first collective): d2s.engine re-checks its side streams once
+    the first steps have run."""
+    if stream is None or not _STREAM_CHECK or all(_streams_overlap(o, stream) for o in beside):
+        return stream
+    return concurrent_stream(beside, purpose + " (re-picked)")
+
+
+def pg_stream_shares_queue(stream, group=None, cycles=3000000):
+    """Does the process group's RCCL stream sit on the hardware queue of `stream`?  (torch picks that stream from its pool at the
+    group's first collective; nothing lets a caller choose it.)  If it does, every collective - which first waits for the gradient
+    streams - holds up whatever `stream` issues after it: measured -17 % on the step.  Probe: a spin on a helper stream, a tiny
+    all_reduce issued behind it (RCCL's stream now waits for the spin), then a spin on `stream` - which ends late only if it had to
+    queue behind that wait.  One collective per call: every rank of the group must make the same calls."""
+    import torch.distributed as dist
+    helper = concurrent_stream([stream], "probe helper")
+    t = torch.zeros(64, device=torch.device("cuda", torch.cuda.current_device()))
+    with torch.cuda.stream(helper):                   # the group's stream exists (and is set up) after its first collective
+        dist.all_reduce(t, group=group, async_op=True).wait()
+        torch.cuda._sleep(1000)
+    with torch.cuda.stream(stream):
+        torch.cuda._sleep(1000)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    with torch.cuda.stream(helper):
+        ev[0].record()
+        torch.cuda._sleep(cycles)
+        ev[1].record()
+        w = dist.all_reduce(t, group=group, async_op=True)
+    with torch.cuda.stream(stream):
+        torch.cuda._sleep(cycles)
+        ev[2].record()
+    with torch.cuda.stream(helper):
+        w.wait()
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[2]) > 1.6 * ev[0].elapsed_time(ev[1])
+
+
+def recheck_weight_grad_stream(beside):
+    if _WGRAD["stream"] is not None and not _WGRAD["on"]:
+        _WGRAD["stream"] = recheck_stream(_WGRAD["stream"], beside, "weight gradients")
+
+
 _WGRAD = {"on": False, "stream": None, "used": False}
 _WGRAD_ENABLED = os.environ.get("D2S_WGRAD_STREAM", "1") != "0"
 _ATTN_BWD_STREAMS = os.environ.get("D2S_ATTN_BWD_STREAMS", "0") == "1"      # dQ and dK/dV kernels of the attention backward side by side:
@@ -344,7 +433,7 @@ class async_weight_grads:
     def __enter__(self):
         if _WGRAD_ENABLED and torch.cuda.is_available():
             if _WGRAD["stream"] is None:
-                _WGRAD["stream"] = torch.cuda.Stream()
+                _WGRAD["stream"] = concurrent_stream([torch.cuda.current_stream()] + list(_WGRAD.get("beside", [])), "weight gradients")
             _WGRAD["on"], _WGRAD["used"] = True, False
         return self
 
