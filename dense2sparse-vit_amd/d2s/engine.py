@@ -506,19 +506,37 @@ class TrainStep:
         flag = torch.tensor([1.0 if bad else 0.0], device=self.arena.params.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.reducer.group)
         self.pg_probe = {"caller_stream_shares_rccl_queue": bool(bad), "moved": False}
-        if float(flag.item()) == 0.0:
+        if float(flag.item()) != 0.0:
+            chosen = None
+            for _ in range(3):
+                cand = torch.cuda.Stream()
+                if not ops.pg_stream_shares_queue(cand, self.reducer.group) and chosen is None:
+                    chosen = cand
+            if bad and chosen is not None:
+                self._capture_stream, self._step_on_side = chosen, True
+                self._teacher_stream = ops.recheck_stream(self._teacher_stream, [chosen], "teacher forward")
+                self.reducer.stream = ops.recheck_stream(self.reducer.stream, [chosen], "gradient exchange")
+                ops.recheck_weight_grad_stream([chosen])
+                self.pg_probe["moved"] = True
+        # the weight-gradient stream must not sit behind RCCL either: every bucket's collective would hold up the weight gradients issued
+        # after it for as long as the exchange takes (the same fixed number of probes on every rank)
+        if not ops._WGRAD_ENABLED:
             return
-        chosen = None
-        for _ in range(3):
-            cand = torch.cuda.Stream()
-            if not ops.pg_stream_shares_queue(cand, self.reducer.group) and chosen is None:
-                chosen = cand
-        if bad and chosen is not None:
-            self._capture_stream, self._step_on_side = chosen, True
-            self._teacher_stream = ops.recheck_stream(self._teacher_stream, [chosen], "teacher forward")
-            self.reducer.stream = ops.recheck_stream(self.reducer.stream, [chosen], "gradient exchange")
-            ops.recheck_weight_grad_stream([chosen])
-            self.pg_probe["moved"] = True
+        step_stream = self._capture_stream if self._step_on_side else cur
+        wg = ops.ensure_weight_grad_stream([step_stream])
+        bad_wg = ops.pg_stream_shares_queue(wg, self.reducer.group)
+        flag.fill_(1.0 if bad_wg else 0.0)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.reducer.group)
+        self.pg_probe["weight_grad_stream_shares_rccl_queue"] = bool(bad_wg)
+        if float(flag.item()) != 0.0:
+            chosen = None
+            for _ in range(3):
+                cand = ops.concurrent_stream([step_stream], "weight gradients (off the RCCL queue)")
+                if not ops.pg_stream_shares_queue(cand, self.reducer.group) and chosen is None:
+                    chosen = cand
+            if bad_wg and chosen is not None:
+                ops.set_weight_grad_stream(chosen)
+                self.pg_probe["weight_grad_stream_moved"] = True
 
     def _eager_step(self, images, labels, next_images=None):
         self.last_step_captured = False

@@ -388,12 +388,13 @@ def recheck_stream(stream, beside, purpose):
     return concurrent_stream(beside, purpose + " (re-picked)")
 
 
-def pg_stream_shares_queue(stream, group=None, cycles=3000000):
+def pg_stream_shares_queue(stream, group=None, cycles=20000000):
     """Does the process group's RCCL stream sit on the hardware queue of `stream`?  (torch picks that stream from its pool at the
     group's first collective; nothing lets a caller choose it.)  If it does, every collective - which first waits for the gradient
     streams - holds up whatever `stream` issues after it: measured -17 % on the step.  Probe: a spin on a helper stream, a tiny
     all_reduce issued behind it (RCCL's stream now waits for the spin), then a spin on `stream` - which ends late only if it had to
-    queue behind that wait.  One collective per call: every rank of the group must make the same calls."""
+    queue behind that wait.  The spins are long (~10 ms) so that the host time of the all_reduce call between the two launches cannot be
+    mistaken for queueing.  Two collectives per call: every rank of the group must make the same calls."""
     import torch.distributed as dist
     helper = concurrent_stream([stream], "probe helper")
     t = torch.zeros(64, device=torch.device("cuda", torch.cuda.current_device()))
@@ -415,7 +416,23 @@ def pg_stream_shares_queue(stream, group=None, cycles=3000000):
     with torch.cuda.stream(helper):
         w.wait()
     torch.cuda.synchronize()
+    if os.environ.get("D2S_STREAM_DEBUG") == "1":
+        import sys
+        print(f"[d2s] rccl-queue probe: helper spin {ev[0].elapsed_time(ev[1]):.2f} ms, start -> end of the probed stream's spin {ev[0].elapsed_time(ev[2]):.2f} ms",
+              file=sys.stderr, flush=True)
     return ev[0].elapsed_time(ev[2]) > 1.6 * ev[0].elapsed_time(ev[1])
+
+
+def ensure_weight_grad_stream(beside):
+    """The weight-gradient stream, created now (instead of at the first backward) if it does not exist yet."""
+    if _WGRAD["stream"] is None:
+        _WGRAD["stream"] = concurrent_stream(list(beside), "weight gradients")
+    return _WGRAD["stream"]
+
+
+def set_weight_grad_stream(stream):
+    assert not _WGRAD["on"]
+    _WGRAD["stream"] = stream
 
 
 def recheck_weight_grad_stream(beside):
