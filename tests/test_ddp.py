@@ -114,3 +114,51 @@ def test_two_ranks_match_single_process_on_concatenated_batch(collective, port):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "[ddp_check]" in out.stdout
+
+
+def _rccl_single_rank_worker(q, port):
+    """Child process (an RCCL group must not leak into the pytest process): two steps of a data-parallel TrainStep on a one-rank RCCL group
+    against the plain TrainStep on the same batches - same kernels, the collectives are identities, so everything is bit-identical -
+    plus the stream placement (d2s.engine.TrainStep._place_beside_process_group) having run and reported."""
+    import types
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from d2s import ops
+        from d2s.engine import TrainStep
+        from tests.test_model_gpu import build_models, make_args, _t
+        from d2s import synth
+        case = cases.MODEL_CASES["micro2"]
+        cfg = case["cfg"]
+        data = [(_t(synth.images(case["batch"], 3, cfg["img_size"], seed=700 + i)).to(dev), _t(synth.labels(case["batch"], cfg["num_classes"], seed=700 + i)).to(dev))
+                for i in range(3)]
+        plain = TrainStep(*build_models(case, dev)[:2], make_args(cfg), graph=False, warmup_steps=0)
+        ddp = TrainStep(*build_models(case, dev)[:2], make_args(cfg), graph=False, warmup_steps=0, distributed=True)
+        ddp.reducer.force = True
+        same = True
+        for x, y in data:
+            a, b = plain(x, y), ddp(x, y)
+            torch.cuda.synchronize()
+            same = same and torch.equal(a["loss"], b["loss"]) and torch.equal(plain.arena.params, ddp.arena.params)
+        probe = ddp.pg_probe
+        picks = list(ops.stream_picks)
+        q.put((same, probe, picks, ddp.reducer._n_collectives))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_single_rank_rccl_step_is_bit_identical_and_places_its_streams():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_rank_worker, args=(q, 29631))
+    p.start()
+    same, probe, picks, n_coll = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0
+    assert same, "the data-parallel step on a one-rank RCCL group must reproduce the plain step bit for bit"
+    assert n_coll > 0, "the reducer must have issued its collectives (force)"
+    assert probe is not None and "caller_stream_shares_rccl_queue" in probe and "weight_grad_stream_shares_rccl_queue" in probe, probe
+    assert any(p[0].startswith("teacher forward") for p in picks) and all(p[2] for p in picks), picks       # every pick verified on the device
