@@ -54,6 +54,16 @@ def patch_drop_mask(kept_token_indices, num_patches):
     return masks
 
 
+
+def _scores(predictor, x):
+    """predictor.forward_tokens(x); the reference's predictor falls through and returns None without topk_selection (:537) and the
+    caller then fails on the unpacking - same outcome here, with a message that says what to pass."""
+    out = predictor.forward_tokens(x)
+    if out is None:
+        raise RuntimeError("the score predictor was built with topk_selection=False: the reference's PredictorLG.forward returns None on that "
+                           "path (vit_models/dynamic_vit.py:537), so the pruning stages cannot run - pass --topk-selection / topk_selection=True")
+    return out
+
 class Mlp(nn.Module):
     """:159-175."""
 
@@ -384,7 +394,7 @@ class VisionTransformerDiffPruning(_ViTBase):
                 x.register_hook(lambda g, i=i, cb=self.grad_ready_hook: (cb(i), None)[1])
             if i in self.pruning_loc:
                 num_keep_node = int(self.init_n * self.token_ratio[p_count])   # :852
-                pred_logits, pred_score = self.score_predictor[p_count].forward_tokens(x)   # :855
+                pred_logits, pred_score = _scores(self.score_predictor[p_count], x)   # :855
                 kept, dropped = DF.select_topk(pred_score, num_keep_node)     # :858-862
                 if self.kept_token_override is not None:
                     kept = self.kept_token_override[p_count].to(device=x.device, dtype=torch.int64).contiguous()
@@ -433,7 +443,7 @@ class VisionTransformerDiffPruning(_ViTBase):
                 if self.grad_ready_hook is not None and x.requires_grad:
                     x.register_hook(lambda g, i=i, cb=self.grad_ready_hook: (cb(i), None)[1])
                 if i in self.pruning_loc:
-                    pred_logits, pred_score = self.score_predictor[p_count].forward_tokens(x)      # :855
+                    pred_logits, pred_score = _scores(self.score_predictor[p_count], x)      # :855
                     policy, counts = ops.select_threshold(pred_score.detach().contiguous(), thr, lead=1)   # :881-893 -> [1, mask]
                     self.keep_ratios = counts.float() / N                                          # :886
                     self.pred_logits.append(pred_logits)
@@ -451,7 +461,7 @@ class VisionTransformerDiffPruning(_ViTBase):
         cu = None
         for i, blk in enumerate(self.blocks):
             if i in self.pruning_loc:
-                pred_logits, pred_score = self.score_predictor[p_count].forward_tokens(x)
+                pred_logits, pred_score = _scores(self.score_predictor[p_count], x)
                 mask, counts = ops.select_threshold(pred_score.contiguous(), thr)                  # :936-938 (score := pred_score)
                 self.keep_ratios = counts.float() / N                                              # :941
                 self.pred_logits.append(pred_logits)

@@ -17,6 +17,8 @@ from .token_transformer import Token_transformer
 from .transformer_block import Block, get_sinusoid_encoding
 
 
+from .dynamic_vit import _scores
+
 class _Unfold(nn.Module):
     """nn.Unfold(kernel_size, stride, padding) followed by .transpose(1, 2) (:85,92,99), reading image or token layout."""
 
@@ -151,7 +153,7 @@ class T2T_ViT_DiffPruning(T2T_ViT):
             if self.grad_ready_hook is not None and x.requires_grad:
                 x.register_hook(lambda g, i=i, cb=self.grad_ready_hook: (cb(i), None)[1])
             if i in self.pruning_loc:
-                pred_logits, pred_score = self.score_predictor[p].forward_tokens(x)
+                pred_logits, pred_score = _scores(self.score_predictor[p], x)
                 kept, dropped = DF.select_topk(pred_score, int(self.init_n * self.token_ratio[p]))
                 self.kept_token_indices.append(kept)
                 self.dropped_token_indices.append(dropped)
