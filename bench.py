@@ -593,6 +593,7 @@ def main():
                 for ms, lay, M, N, K, n, us, tf in sorted(rows, reverse=True):
                     f.write(f"{lay} {M:6d} {N:5d} {K:6d} {n:5.1f} {us:8.1f} {tf:7.1f} {ms:7.3f}\n")
         line["c_abi_calls_per_step"] = round(timer.launch_calls / args.steps, 1)
+        line["hbm_reserved_GiB"] = round(torch.cuda.memory_stats()["reserved_bytes.all.peak"] / 2**30, 1)      # caching-allocator pool (the host runs steps ahead)
         # side streams are chosen so that they sit on another hardware queue than the main stream (d2s.ops.concurrent_stream): purpose, candidates tried, verified
         line["side_streams"] = [{"for": p, "candidates_tried": n, "runs_beside_main": ok} for p, n, ok in ops.stream_picks]
         sc = summ.get(("scatter_unpack", ""))
