@@ -545,94 +545,6 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 1) void gemm_f3
     store_tile_dispatch_lds<MT, NT>(epi, p, Cb, acc, row0 + wm * WM, col0 + wn * WN, lane, smem + wave * epi_stage_floats(NT));
 }
 
-// Experimental (D2S_GEMM_RK16=1): the [row][16 k] image with v_mfma_f32_16x16x4_f32 - the small MFMA the vendor library uses on every fp32 shape
-// (profiles/r03_n_vendor_library_yardstick.txt).  Lane l holds row l & 15 of a 16-row block and the 16-byte chunk l >> 4 of the stage: ONE
-// ds_read_b128 per block and stage feeds four MFMA steps (step s multiplies k = 4 (l >> 4) + s on both operands), so a 64x64 wave tile reads
-// 8 x b128 per 64 MFMAs - the same LDS traffic as the 32x32x2 form, on 16 independent 4-register accumulators.  Chunk c of row r sits at
-// c ^ F[(r >> 2) & 3], F = {0, 2, 3, 1}: conflict-free for ds_write_b128 and for the four 16-lane groups of this lane -> (row, chunk) map.
-__device__ __forceinline__ int swz16(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
-
-template <int BM, int BN>
-__global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 1) void gemm_f32_rk16_kernel(GemmArgs p) {
-    constexpr int WM = BM / 2, WN = BN / 2, MB = WM / 16, NB = WN / 16;
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
-    float* As = smem;                 // [2][BM][BK]
-    float* Bs = smem + 2 * BK * BM;   // [2][BN][BK]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kq = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-    const int nwg = nbm * nbn;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int row0 = (bid / nbn) * BM, col0 = (bid % nbn) * BN;
-    const int kbeg = blockIdx.z * p.k_per_slice;
-    const int kend = min(p.K, kbeg + p.k_per_slice);
-    const int nk = (kend - kbeg + BK - 1) / BK;
-
-    f32x4 acc[MB][NB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    f32x4 ra[BM / 64], rb[BN / 64];
-    long offa[BM / 64], offb[BN / 64];
-    tile_offsets<0, BM>(p.lda, row0, p.M, tid, offa);
-    tile_offsets<0, BN>(p.ldb, col0, p.N, tid, offb);
-    if (nk > 0) {
-        load_tile_fast<0, BM>(p.A, p.lda, kbeg, offa, ra);
-        load_tile_fast<0, BN>(p.B, p.ldb, kbeg, offb, rb);
-#pragma unroll
-        for (int i = 0; i < BM / 64; ++i) { const int f = tid + i * 256, row = f >> 2, c = f & 3; *reinterpret_cast<f32x4*>(&As[row * BK + ((c ^ swz16(row)) << 2)]) = ra[i]; }
-#pragma unroll
-        for (int i = 0; i < BN / 64; ++i) { const int f = tid + i * 256, row = f >> 2, c = f & 3; *reinterpret_cast<f32x4*>(&Bs[row * BK + ((c ^ swz16(row)) << 2)]) = rb[i]; }
-    }
-    __syncthreads();
-
-    int a_off[MB], b_off[NB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i) { const int row = wm * WM + i * 16 + li; a_off[i] = row * BK + ((kq ^ swz16(row)) << 2); }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) { const int row = wn * WN + j * 16 + li; b_off[j] = row * BK + ((kq ^ swz16(row)) << 2); }
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const int kn = kbeg + min(kt + 1, nk - 1) * BK;
-        load_tile_fast<0, BM>(p.A, p.lda, kn, offa, ra);
-        load_tile_fast<0, BN>(p.B, p.ldb, kn, offb, rb);
-        const float* Ac = As + cur * BK * BM;
-        const float* Bc = Bs + cur * BK * BN;
-        f32x4 av[MB], bv[NB];
-#pragma unroll
-        for (int i = 0; i < MB; ++i) av[i] = *reinterpret_cast<const f32x4*>(Ac + a_off[i]);
-#pragma unroll
-        for (int j = 0; j < NB; ++j) bv[j] = *reinterpret_cast<const f32x4*>(Bc + b_off[j]);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j) acc[i][j] = mfma16(av[i][s], bv[j][s], acc[i][j]);
-        if (kt + 1 < nk) {
-            float* An = As + (cur ^ 1) * BK * BM;
-            float* Bn = Bs + (cur ^ 1) * BK * BN;
-#pragma unroll
-            for (int i = 0; i < BM / 64; ++i) { const int f = tid + i * 256, row = f >> 2, c = f & 3; *reinterpret_cast<f32x4*>(&An[row * BK + ((c ^ swz16(row)) << 2)]) = ra[i]; }
-#pragma unroll
-            for (int i = 0; i < BN / 64; ++i) { const int f = tid + i * 256, row = f >> 2, c = f & 3; *reinterpret_cast<f32x4*>(&Bn[row * BK + ((c ^ swz16(row)) << 2)]) = rb[i]; }
-        }
-        __syncthreads();
-    }
-    float* Cb = p.C + (long)blockIdx.z * p.slab_stride;
-    const int epi = (gridDim.z > 1) ? (int)EPI_NONE : p.epi;
-    static_assert(4 * 16 * (WN + 4) <= 2 * BK * (BM + BN), "epilogue staging must fit the operand buffers");
-    store_tile_dispatch_lds16<MB, NB>(epi, p, Cb, acc, row0 + wm * WM, col0 + wn * WN, lane, smem + wave * 16 * (WN + 4));
-}
-
 // Deterministic split-K combine: C (+)= sum over slabs in slab order.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C,
                                                             long ldc, int M, int N, int slabs, long slab_stride,
@@ -907,20 +819,8 @@ inline bool use_mfma16() {
     static const int on = [] { const char* e = getenv("D2S_GEMM_MFMA16"); return e ? atoi(e) : 0; }();
     return on != 0;
 }
-inline bool use_rk16() {
-    static const int on = [] { const char* e = getenv("D2S_GEMM_RK16"); return e ? atoi(e) : 0; }();
-    return on != 0;
-}
 template <int ALAY, int BLAY>
 inline void launch_gemm(const Tile& t, dim3 grid, hipStream_t stream, const GemmArgs& p, bool fast) {
-    if (fast && p.vec_epilogue && ALAY == 0 && BLAY == 0 && use_rk() && use_rk16()) {
-        dim3 block(256);
-        if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((gemm_f32_rk16_kernel<128, 128>), grid, block, 0, stream, p);
-        else if (t.bm == 128) hipLaunchKernelGGL((gemm_f32_rk16_kernel<128, 64>), grid, block, 0, stream, p);
-        else if (t.bn == 128) hipLaunchKernelGGL((gemm_f32_rk16_kernel<64, 128>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((gemm_f32_rk16_kernel<64, 64>), grid, block, 0, stream, p);
-        return;
-    }
     if (fast && p.vec_epilogue && ALAY == 0 && use_rk()) launch_gemm_rk<BLAY>(t, grid, stream, p);
     else if (fast && p.vec_epilogue && use_mfma16()) launch_gemm16<ALAY, BLAY>(t, grid, stream, p);
     else if (fast) launch_gemm_f<ALAY, BLAY, true>(t, grid, stream, p);
