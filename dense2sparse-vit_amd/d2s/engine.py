@@ -465,7 +465,7 @@ class TrainStep:
         self.arena.check_alias()
         if images.is_cuda and self._steps_seen == 0 and self.reducer is not None:
             self._place_beside_process_group()
-        if images.is_cuda and self.graph is False and self._steps_seen in (1, 3):
+        if images.is_cuda and self.graph is False and self._steps_seen in (1, 2):
             # the side streams were picked before anything else had run; an RCCL communicator (and whatever else creates streams late)
             # can have moved onto their hardware queues since: verify once the first step(s) are behind us
             main = self._capture_stream if self._step_on_side else torch.cuda.current_stream()
