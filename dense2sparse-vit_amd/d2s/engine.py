@@ -332,7 +332,7 @@ class GradReducer:
         exposed = sum(max(0.0, a.elapsed_time(b)) for a, b in self._exposed)
         n = max(self.world, 1)
         out = {"allreduce_bytes_per_step": self._bytes / steps, "buckets_per_step": len(self._events) / steps,
-               "collectives_per_step": self._n_collectives / steps, "collective": self.collective, "bucket_mb": self.bucket_mb,
+               "collectives_per_step": round(self._n_collectives / steps, 2), "collective": self.collective, "bucket_mb": self.bucket_mb,
                "allreduce_ms_per_step": round(t_ms / steps, 3), "exposed_ms_per_step": round(exposed / steps, 3),
                "bus_GBps": round(2.0 * (n - 1) / n * self._bytes / (t_ms * 1e-3) / 1e9, 1) if t_ms > 0 else None,
                "backend": "nccl (RCCL)", "world": n}
