@@ -477,6 +477,7 @@ def main():
         ops._BLOCK_COMPOSITE = False        # the per-kernel events sit in the per-op wrappers (see the instrumented pass below)
     if distributed:
         ts.reducer.timing = True
+        ts.reducer._n_collectives = 0       # count the timed region's collectives only (the warm-up steps issued some)
     host_s = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
